@@ -1,0 +1,145 @@
+/* tmix.h -- C ABI of libtmix_hip.so, the MI355X (gfx950) kernels behind the Tweedie-mix
+ * denoising loop.
+ *
+ * The reference (KwonGihyun/TweedieMix) is pure Python and has no FFI of its own: its seams are
+ * the Python call sites listed below.  Each entry point here replaces the arithmetic behind one of
+ * those call sites; tweediemix_amd/ binds them with ctypes (see INTEGRATION.md for the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every pointer is a BORROWED device pointer (the caller
+ *    -- PyTorch's allocator in our host code -- owns the memory).  Nothing here allocates or frees.
+ *  - every launch function takes the hipStream_t to enqueue on (as void*), is asynchronous, never
+ *    synchronises, and is capturable into a hipGraph.
+ *  - return value: 0 = ok, <0 = TMIX_E* argument error (nothing was launched), >0 = hipError_t.
+ *    tmix_last_error_string() gives a thread-local description of the last non-zero return.
+ *  - bf16 = raw uint16 storage, row-major.  Activations are NHWC ([B, H*W, C]); Linear weights are
+ *    torch layout [N_out, K_in]; conv weights are OHWI [C_out, 3, 3, C_in].
+ */
+#ifndef TMIX_H
+#define TMIX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMIX_VERSION 100
+
+enum { TMIX_OK = 0, TMIX_EINVAL = -1, TMIX_ESHAPE = -2, TMIX_EARCH = -3, TMIX_EALIGN = -4 };
+enum { TMIX_F32 = 0, TMIX_F16 = 1, TMIX_BF16 = 2 };
+
+int tmix_version(void);
+const char* tmix_last_error_string(void);
+/* 0 if the current device is gfx950, TMIX_EARCH otherwise, >0 on HIP errors. */
+int tmix_check_device(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused CFG + Tweedie x0 + mask blend + DDIM update.
+ * Replaces fusion_generation/fusion_sampling.py:376-385,430,471-472 (fusion branch),
+ * :392-403 (resampling, first half), :406-412 / :424-430 / :436-447 (plain CFG / jumping).
+ *   x        [n]            fp32 latent (one sample, n = C*h*w)
+ *   eps      [rows, n]      UNet output, dtype eps_dtype (row 0 = unconditional)
+ *   masks    [K, hw]        fp32 blend weights (FUSION only; broadcast over the C channels)
+ *   out_x    [n]            fp32 next latent  (x0 itself when is_last)
+ *   out_x0   [n] or NULL    fp32 Tweedie estimate
+ * modes: FUSION   rows=K+1 : x0 = sum_c m_c * T(x, cfg(e0,e_{1+c}))
+ *        PLAIN    rows=2   : x0 = T(x, cfg(e0,e1))
+ *        RESAMPLE rows=K+1 : x0 = (K-1)*T(x,cfg(e0,e1)) - sum_{c<K-1} T(x,cfg(e0,e_{2+c}))
+ *   with T(x,e) = (x - s1*e)/sa and out = sa_next*x0 + s1_next*e0.
+ * sa=sqrt(at), s1=sqrt(1-at), *_next likewise for the target timestep (computed by the host in fp32).
+ * eps_dtype F16 reproduces the reference's autocast rounding points (CFG combine and s1*e in
+ * fp16, everything else fp32); BF16/F32 eps are combined in fp32.
+ */
+enum { TMIX_STEP_FUSION = 0, TMIX_STEP_PLAIN = 1, TMIX_STEP_RESAMPLE = 2 };
+int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, const float* masks,
+                            float* out_x, float* out_x0, int K, int channels, int64_t hw, int mode,
+                            float g, float sa, float s1, float sa_next, float s1_next, int is_last,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogues:  C[b] = epi(A[b] (MxK) * W[b]^T (NxK)).
+ * Replaces the Linear layers inside the UNet call at fusion_sampling.py:340/374/406/414/440
+ * (diffusers Attention.to_q/to_k/to_v/to_out, FeedForward, proj_in/out, conv_shortcut) and the
+ * per-row concept weights of utils_custom.py:64-83 / utils_lora.py:65-79,113-119 (batch with
+ * strideW != 0 selects one weight set per batch row).
+ * Requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned pointers.
+ */
+enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1 };
+typedef struct {
+    const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
+    const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */
+    void*       C;  int64_t ldc, strideC;        /* bf16 [batch][M][ldc] (N/2 cols when GEGLU)    */
+    const float* bias;  int64_t strideBias;      /* fp32 [N] or NULL                              */
+    const void* residual; int64_t ldr, strideR;  /* bf16 [batch][M][ldr] or NULL (added in fp32)  */
+    const float* rowgroup_bias;                  /* fp32 [M/rows_per_group][N] or NULL            */
+    int32_t rows_per_group;
+    void*   Ct; int64_t ldct, strideCt;          /* transposed output for columns >= n_trans_begin */
+    int32_t n_trans_begin;                       /*   Ct[b][n - n_trans_begin][m]; <0 = none       */
+    int32_t M, N, K, batch;
+    int32_t epilogue;
+} tmix_gemm_desc;
+int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 convolution, NHWC bf16, implicit GEMM on MFMA (pad 1).
+ * Replaces diffusers ResnetBlock2D.conv1/conv2, Downsample2D.conv (mode 1) and Upsample2D
+ * (nearest x2 + conv, mode 2) inside the same UNet call sites.  Cin % 64 == 0.
+ */
+enum { TMIX_CONV_S1 = 0, TMIX_CONV_S2 = 1, TMIX_CONV_UP2 = 2 };
+typedef struct {
+    const void* X;   /* bf16 [B][H][W][Cin]                                   */
+    const void* Wt;  /* bf16 [Cout][3][3][Cin]                                */
+    void*       Y;   /* bf16 [B][Ho][Wo][Cout]  Ho = H (S1), H/2 (S2), 2H (UP2) */
+    const float* bias;           /* fp32 [Cout] or NULL                       */
+    const float* batch_bias;     /* fp32 [B][Cout] (time embedding) or NULL   */
+    const void* residual;        /* bf16 like Y or NULL                       */
+    int32_t B, H, W, Cin, Cout, mode;
+} tmix_conv_desc;
+int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
+
+/* conv_in: fp32 NCHW latent [B,Cin<=8,H,W] -> bf16 NHWC [B,H,W,Cout]; weights fp32 OHWI. */
+int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
+                 int B, int Cin, int H, int W, int Cout, void* stream);
+/* conv_out: bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,Cout<=8,H,W]; weights bf16 OHWI. */
+int tmix_conv_out(const void* x_nhwc, const void* w_ohwi, const float* bias, float* y_nchw,
+                  int B, int Cin, int H, int W, int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Flash attention forward, head dim 64, bf16 in/out, fp32 softmax (never materialises S x S).
+ * Replaces the explicit einsum/softmax/einsum of utils_custom.py:93-103 and utils_lora.py:101-111
+ * and xformers' memory-efficient attention for attn1 (fusion_sampling.py:120,133,210).
+ *   Q  [B][Sq][ldq]   head h at columns h*64..h*64+63
+ *   K  [B][Skv][ldk]  same column convention
+ *   Vt [B][H*64][ldvt] V TRANSPOSED (row = h*64+d, column = key); ldvt >= Skv rounded up to 8 and
+ *                      the padding columns must hold finite values
+ *   O  [B][Sq][ldo]
+ */
+int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                  const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                  int B, int H, int Sq, int Skv, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation / small ops (diffusers GroupNorm(32)+SiLU, LayerNorm, Timesteps, time MLPs).
+ */
+/* ws: fp32 workspace of >= B*groups*2*tmix_groupnorm_ws_chunks(HW) floats. Two inputs are
+ * normalised as one tensor concatenated along C (X2 may be NULL, C2 = 0). */
+int tmix_groupnorm_ws_chunks(int64_t HW);
+int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
+                        const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                        void* stream);
+int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta, int64_t rows, int C,
+                   float eps, void* stream);
+int tmix_concat_channels(const void* X1, int C1, const void* X2, int C2, void* Y, int64_t rows, void* stream);
+/* sinusoidal embedding (flip_sin_to_cos=True, shift 0): out[i] = [cos(v_i f_j) | sin(v_i f_j)], j<dim/2 */
+int tmix_timestep_embedding(const float* values, float* out, int count, int dim, void* stream);
+/* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 16.
+ * act: 0 none, 1 SiLU.  add (nullable): fp32 [M,N] added before act_out. */
+int tmix_linear_small(const float* in, const void* W, const float* bias, const float* add, float* out,
+                      int M, int N, int K, int act_in, int act_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMIX_H */

@@ -1,0 +1,273 @@
+"""GPU parity of every C-ABI kernel against a plain torch fp32 reference of the same op
+(and, for the fused Tweedie step, against the numpy oracle bit-for-bit).
+
+Tolerances: kernels read bf16 operands and accumulate in fp32; outputs are rounded to bf16 once, so
+|err| <= 2 bf16 ulp of the result (rtol 2^-7) plus an absolute term for cancellation.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tweediemix_amd import lib, ops as O
+    lib.check(lib.load().tmix_check_device(), "tmix_check_device")
+    return O
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def close(out, ref, rtol=2 ** -7, atol_frac=2e-3):
+    out = out.float()
+    ref = ref.float()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all()
+    atol = atol_frac * ref.abs().max().item() + 1e-6
+    err = (out - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bad.any(), f"max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g}), {int(bad.sum())} bad"
+
+
+# --------------------------------------------------------------------------- fused tweedie step
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("mode", ["fusion", "plain", "resample"])
+@pytest.mark.parametrize("K,h,w,last", [(3, 16, 16, False), (3, 128, 128, False), (2, 8, 12, True), (5, 5, 7, False)])
+def test_tweedie_step_bit_exact(ops, dt, mode, K, h, w, last):
+    from oracle import tweedie_oracle as TO
+    from tweediemix_amd import lib as L
+    rng = np.random.RandomState(K * 100 + h)
+    x = rng.randn(1, 4, h, w).astype(np.float32)
+    eps = rng.randn(K + 1, 4, h, w).astype(np.float32)
+    masks = (rng.rand(K, 1, h, w) > 0.6).astype(np.float32)
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    eps_t = torch.from_numpy(eps).to(tdt).cuda()
+    eps_r = eps_t.float().cpu().numpy()                 # what the kernel actually reads
+    at, an, g = np.float32(0.2345), np.float32(0.3456), 0.8
+    lowp = np.float16 if dt == "f16" else None
+    if mode == "fusion":
+        ref, ref0 = TO.fused_fusion_step(x, eps_r, masks, g, at, an, last, lowp)
+        m = L.STEP_FUSION
+    elif mode == "plain":
+        ref, ref0 = TO.fused_plain_step(x, eps_r[:2], g, at, an, last, lowp)
+        m = L.STEP_PLAIN
+    else:
+        ref = TO.fused_resample_down(x, eps_r, K, g, at, an, lowp)
+        ref0 = None
+        m = L.STEP_RESAMPLE
+        last = False
+    xt = torch.from_numpy(x).cuda()
+    x0 = torch.empty_like(xt)
+    out = ops.fused_tweedie_step(xt, eps_t, torch.from_numpy(masks).cuda(), m, K, g, at, an, last, out_x0=x0)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref), np.abs(out.cpu().numpy() - ref).max()
+    if ref0 is not None:
+        assert np.array_equal(x0.cpu().numpy(), ref0)
+
+
+def test_tweedie_step_rejects_bad_args(ops):
+    from tweediemix_amd import lib as L
+    x = torch.zeros(1, 4, 8, 8, device="cuda")
+    eps = torch.zeros(2, 4, 8, 8, device="cuda")
+    with pytest.raises(L.TmixError):
+        ops.fused_tweedie_step(x, eps, None, L.STEP_FUSION, 3, 0.8, 0.5, 0.6)      # too few rows
+    with pytest.raises(L.TmixError):
+        ops.fused_tweedie_step(x, eps, None, L.STEP_PLAIN, 3, 0.8, 0.0, 0.6)       # sqrt(alpha) == 0
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
+                                   (1024, 1280, 640), (130, 132, 192)])
+def test_gemm_plain(ops, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    out = ops.gemm(a, w)
+    close(out, a.float() @ w.float().T)
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 384, 640, 256
+    a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    res = rnd(M, N, seed=6)
+    rgb = rnd(3, N, seed=7, dtype=torch.float32)
+    out = ops.gemm(a, w, bias=bias, residual=res, rowgroup_bias=rgb, rows_per_group=128)
+    ref = a.float() @ w.float().T + bias + res.float() + rgb.repeat_interleave(128, 0)
+    close(out, ref)
+
+
+def test_gemm_geglu(ops):
+    M, C = 200, 128
+    a = rnd(M, C, seed=8)
+    w = rnd(8 * C, C, seed=9, scale=C ** -0.5)           # torch layout: rows [0,4C) value, [4C,8C) gate
+    b = rnd(8 * C, seed=10, dtype=torch.float32)
+    from tweediemix_amd.weights import interleave_geglu
+    wi, bi = interleave_geglu(w, b)
+    out = ops.gemm(a, wi, bias=bi, geglu=True)
+    y = a.float() @ w.float().T + b
+    ref = y[:, :4 * C] * F.gelu(y[:, 4 * C:])
+    close(out, ref)
+
+
+def test_gemm_batched_weights_and_transposed_out(ops):
+    Bz, M, C = 3, 100, 128
+    a = rnd(Bz, M, C, seed=11)
+    w = rnd(Bz, 3 * C, C, seed=12, scale=C ** -0.5)      # one weight set per batch row (concept routing)
+    ldvt = 104
+    vt = torch.zeros(Bz, C, ldvt, device="cuda", dtype=BF)
+    qk = ops.gemm(a, w, out_t=vt, n_trans_begin=2 * C)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    close(qk, ref[:, :, :2 * C])
+    close(vt[:, :, :M], ref[:, :, 2 * C:].transpose(1, 2))
+    assert (vt[:, :, M:] == 0).all()
+    # shared weights, strided (column-sliced) A
+    big = rnd(Bz, M, 2 * C, seed=13)
+    out = ops.gemm(big[:, :, C:], w[0])
+    close(out, big[:, :, C:].float() @ w[0].float().T)
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from tweediemix_amd import lib as L
+    with pytest.raises(L.TmixError):
+        ops.gemm(rnd(64, 96), rnd(64, 96))                # K % 64
+    with pytest.raises(L.TmixError):
+        ops.gemm(rnd(64, 64), rnd(66, 64))                # N % 4
+
+
+# --------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 10, 6, 128, 68), (3, 8, 8, 320, 320)])
+def test_conv3x3(ops, mode, B, H, W, Cin, Cout):
+    x = rnd(B, H, W, Cin, seed=20)
+    w = rnd(Cout, 3, 3, Cin, seed=21, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=22, dtype=torch.float32)
+    temb = rnd(B, Cout, seed=23, dtype=torch.float32)
+    Ho, Wo = ops.conv_out_hw(H, W, mode)
+    res = rnd(B, Ho, Wo, Cout, seed=24)
+    out = ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=res, mode=mode)
+    xn = x.float().permute(0, 3, 1, 2)
+    wn = w.float().permute(0, 3, 1, 2)
+    if mode == 2:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xn, wn, bias, stride=2 if mode == 1 else 1, padding=1)
+    ref = ref + temb[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    close(out, ref.permute(0, 2, 3, 1))
+
+
+def test_conv_in_out(ops):
+    B, H, W = 2, 12, 20
+    x = rnd(B, 4, H, W, seed=30, dtype=torch.float32)
+    w = rnd(64, 3, 3, 4, seed=31, scale=1 / 6, dtype=torch.float32)
+    b = rnd(64, seed=32, dtype=torch.float32)
+    y = ops.conv_in(x, w, b)
+    ref = F.conv2d(x, w.permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    close(y, ref)
+    xi = rnd(B, H, W, 96, seed=33)
+    wo = rnd(4, 3, 3, 96, seed=34, scale=(9 * 96) ** -0.5)
+    bo = rnd(4, seed=35, dtype=torch.float32)
+    yo = ops.conv_out(xi, wo, bo)
+    ref = F.conv2d(xi.float().permute(0, 3, 1, 2), wo.float().permute(0, 3, 1, 2), bo, padding=1)
+    assert yo.dtype == torch.float32
+    torch.testing.assert_close(yo, ref, rtol=1e-4, atol=1e-4)
+
+
+# --------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 2, 256, 256), (1, 3, 64, 77), (2, 1, 200, 16), (1, 2, 1024, 1024), (4, 5, 128, 77)])
+def test_attention(ops, B, H, Sq, Skv):
+    Cc = H * 64
+    q = rnd(B, Sq, Cc, seed=40)
+    k = rnd(B, Skv, Cc, seed=41)
+    v = rnd(B, Skv, Cc, seed=42)
+    ld = (Skv + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, ld, device="cuda", dtype=BF)
+    vt[:, :, :Skv] = v.transpose(1, 2)
+    out = ops.attention(q, k, vt, H, Skv, 0.125)
+
+    def heads(t):
+        return t.float().reshape(B, -1, H, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), scale=0.125)
+    close(out, ref.transpose(1, 2).reshape(B, Sq, Cc), rtol=2 ** -6, atol_frac=4e-3)
+
+
+def test_attention_online_softmax_rescale(ops):
+    """a late key with a huge score forces the running max to jump in the last tile (guide rule 26)."""
+    B, H, Sq, Skv = 1, 1, 128, 256
+    q = rnd(B, Sq, 64, seed=43)
+    k = rnd(B, Skv, 64, seed=44)
+    v = rnd(B, Skv, 64, seed=45)
+    k[0, 200] = q[0, 5] * 4.0
+    k[0, 70] = q[0, 9] * 3.0
+    vt = v.transpose(1, 2).contiguous()
+    out = ops.attention(q, k, vt, H, Skv, 0.125)
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None], scale=0.125)[:, 0]
+    close(out, ref, rtol=2 ** -6, atol_frac=4e-3)
+
+
+def test_attention_strided_qkv(ops):
+    """q/k read straight out of a fused [B,S,2C] projection buffer (row stride 2C)."""
+    B, H, S = 2, 2, 192
+    Cc = H * 64
+    qk = rnd(B, S, 2 * Cc, seed=46)
+    v = rnd(B, S, Cc, seed=47)
+    vt = v.transpose(1, 2).contiguous()
+    out = ops.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, H, S, 0.125)
+
+    def heads(t):
+        return t.float().reshape(B, -1, H, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(heads(qk[:, :, :Cc]), heads(qk[:, :, Cc:]), heads(v), scale=0.125)
+    close(out, ref.transpose(1, 2).reshape(B, S, Cc), rtol=2 ** -6, atol_frac=4e-3)
+
+
+# --------------------------------------------------------------------------- norms / small ops
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (1, 100, 64, 0, False), (2, 64, 640, 320, True),
+                                             (1, 1024, 1280, 1280, True), (4, 16, 32, 0, False)])
+def test_groupnorm(ops, B, HW, C1, C2, silu):
+    x1 = rnd(B, HW, C1, seed=50) + 0.5
+    x2 = rnd(B, HW, C2, seed=51) * 2 if C2 else None
+    Cc = C1 + C2
+    g = rnd(Cc, seed=52, dtype=torch.float32)
+    b = rnd(Cc, seed=53, dtype=torch.float32)
+    y = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], -1)
+    ref = F.group_norm(xin.transpose(1, 2), 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref.transpose(1, 2))
+
+
+@pytest.mark.parametrize("rows,Cc", [(77, 640), (1024, 1280), (5, 64), (3, 2048)])
+def test_layernorm(ops, rows, Cc):
+    x = rnd(rows, Cc, seed=54) * 3 + 1
+    g = rnd(Cc, seed=55, dtype=torch.float32)
+    b = rnd(Cc, seed=56, dtype=torch.float32)
+    close(ops.layernorm(x, g, b, 1e-5), F.layer_norm(x.float(), (Cc,), g, b, 1e-5))
+
+
+def test_concat_and_embedding_and_linear_small(ops):
+    a, b = rnd(3, 50, 64, seed=57), rnd(3, 50, 128, seed=58)
+    assert torch.equal(ops.concat_channels(a, b), torch.cat([a, b], -1))
+    vals = torch.tensor([981.0, 1.0, 1024.0, 0.0, 500.0], device="cuda")
+    for dim in (320, 256):
+        e = ops.timestep_embedding(vals, dim)
+        half = dim // 2
+        freq = torch.exp(-np.log(10000.0) * torch.arange(half, device="cuda", dtype=torch.float32) / half)
+        arg = vals[:, None] * freq[None]
+        ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
+        torch.testing.assert_close(e, ref, rtol=0, atol=2e-4)
+    for M in (1, 4, 6):
+        x = rnd(M, 320, seed=59, dtype=torch.float32)
+        w = rnd(1280, 320, seed=60, scale=320 ** -0.5)
+        bias = rnd(1280, seed=61, dtype=torch.float32)
+        add = rnd(M, 1280, seed=62, dtype=torch.float32)
+        y = ops.linear_small(x, w, bias, add, act_in=True, act_out=True)
+        ref = F.silu(F.silu(x) @ w.float().T + bias + add)
+        torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,26 @@
+// capi.cpp -- version / error plumbing of the C ABI (include/tmix.h)
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void tmix_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int tmix_version(void) { return TMIX_VERSION; }
+extern "C" const char* tmix_last_error_string(void) { return g_err; }
+
+extern "C" int tmix_check_device(void) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) TMIX_FAIL((int)e, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) TMIX_FAIL((int)e, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) TMIX_FAIL(TMIX_EARCH, "device arch %s is not gfx950", p.gcnArchName);
+    return TMIX_OK;
+}

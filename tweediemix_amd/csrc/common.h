@@ -1,0 +1,43 @@
+// common.h -- shared helpers for the gfx950 kernels of libtmix_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/tmix.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short  bf16x8;   // one MFMA A/B fragment (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) float  f32x4;    // 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator fragment
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// thread-local error string (host side)
+void tmix_set_error(const char* fmt, ...);
+#define TMIX_FAIL(code, ...) do { tmix_set_error(__VA_ARGS__); return (code); } while (0)
+#define TMIX_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    tmix_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids land on
+// the same XCD (hardware places physical id b on XCD b % 8).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

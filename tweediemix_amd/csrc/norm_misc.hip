@@ -1,0 +1,412 @@
+// norm_misc.hip -- HBM-bound helpers of the UNet forward on gfx950: GroupNorm(+SiLU) on NHWC,
+// LayerNorm, channel concat, sinusoidal timestep embedding, the tiny time/add-embedding MLPs,
+// conv_in (4 -> 320, fp32 VALU) and conv_out (320 -> 4, MFMA with fp32 NCHW output).
+// All bf16 traffic is 16 bytes per lane.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
+    f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
+    f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
+    f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]); v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+    return v;
+}
+
+// ------------------------------------------------------------------------------ GroupNorm
+constexpr int GN_MAX_C = 4096;
+
+__host__ __device__ inline int gn_chunks(int64_t HW) {
+    int64_t c = HW / 32;
+    if (c < 1) c = 1;
+    if (c > 128) c = 128;
+    return (int)c;
+}
+
+// partial sums per (batch, chunk of pixels, group): ws[((b*chunks + ch)*groups + g)*2 + {0,1}]
+__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
+                                                       float* __restrict__ ws, int64_t HW, int groups, int chunks) {
+    __shared__ float s_sum[GN_MAX_C], s_sq[GN_MAX_C];
+    const int C = C1 + C2, nvec = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int64_t ppc = (HW + chunks - 1) / chunks;
+    const int64_t p0 = (int64_t)ch * ppc;
+    int64_t p1 = p0 + ppc; if (p1 > HW) p1 = HW;
+    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    // fixed vector column per thread so the 8 per-channel sums stay in registers across pixels
+    const int plane = nvec <= 256 ? 256 / nvec : 1;          // pixel lanes per block
+    for (int v0 = 0; v0 < nvec; v0 += 256) {
+        const int v = v0 + (nvec <= 256 ? tid % nvec : tid);
+        const int pl = nvec <= 256 ? tid / nvec : 0;
+        if (v < nvec && pl < plane) {
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int c0 = v * 8;
+            const bf16_t* src; int cs, cl;
+            if (c0 < C1) { src = X1 + (int64_t)b * HW * C1; cs = C1; cl = c0; }
+            else         { src = X2 + (int64_t)b * HW * C2; cs = C2; cl = c0 - C1; }
+            for (int64_t p = p0 + pl; p < p1; p += plane) {
+                const uint4 raw = *(const uint4*)(src + p * cs + cl);
+                float f[8]; unpack8(raw, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&s_sum[c0 + j], a[j]); atomicAdd(&s_sq[c0 + j], q[j]); }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float s = 0.f, q = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += s_sum[c]; q += s_sq[c]; }
+        float* o = ws + (((int64_t)b * chunks + ch) * groups + tid) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
+                                                       bf16_t* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ws, int64_t HW, int groups, int chunks, float eps, int silu) {
+    __shared__ float s_scale[GN_MAX_C], s_shift[GN_MAX_C];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = C1 + C2, nvec = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < groups) {
+        double s = 0.0, q = 0.0;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const float* o = ws + (((int64_t)b * chunks + ch) * groups + tid) * 2;
+            s += (double)o[0]; q += (double)o[1];
+        }
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * gamma[c];
+        s_scale[c] = sc;
+        s_shift[c] = beta[c] - s_mean[g] * sc;
+    }
+    __syncthreads();
+    const int64_t total = HW * nvec;
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per;
+    int64_t i1 = i0 + per; if (i1 > total) i1 = total;
+    for (int64_t i = i0 + tid; i < i1; i += 256) {
+        const int64_t p = i / nvec; const int v = (int)(i - p * nvec);
+        const int c0 = v * 8;
+        const bf16_t* src = (c0 < C1) ? X1 + ((int64_t)b * HW + p) * C1 + c0 : X2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
+        const uint4 raw = *(const uint4*)src;
+        float f[8]; unpack8(raw, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = f[j] * s_scale[c0 + j] + s_shift[c0 + j];
+            if (silu) y = silu_f(y);
+            f[j] = y;
+        }
+        *(uint4*)(Y + ((int64_t)b * HW + p) * C + c0) = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// one wave per row, row kept in registers (exact two-pass variance); C <= 2048, C % 8 == 0
+__global__ void __launch_bounds__(256) layernorm_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 3;
+    float f[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = i * 64 + lane;
+        if (v < nvec) {
+            const uint4 raw = *(const uint4*)(X + row * C + v * 8);
+            unpack8(raw, f[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[i][j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = i * 64 + lane;
+        if (v < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = i * 64 + lane;
+        if (v < nvec) {
+            const float4 g0 = *(const float4*)(gamma + v * 8), g1 = *(const float4*)(gamma + v * 8 + 4);
+            const float4 b0 = *(const float4*)(beta + v * 8), b1 = *(const float4*)(beta + v * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (f[i][j] - mean) * rstd * gg[j] + bb[j];
+            *(uint4*)(Y + row * C + v * 8) = pack8(y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ concat
+__global__ void __launch_bounds__(256) concat_kernel(const uint4* __restrict__ X1, int v1, const uint4* __restrict__ X2, int v2,
+                                                     uint4* __restrict__ Y, int64_t rows) {
+    const int nv = v1 + v2;
+    const int64_t total = rows * nv;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / nv; const int v = (int)(i - r * nv);
+        Y[i] = v < v1 ? X1[r * v1 + v] : X2[r * v2 + (v - v1)];
+    }
+}
+
+// ------------------------------------------------------------------------------ timestep embedding
+__global__ void timestep_embedding_kernel(const float* __restrict__ values, float* __restrict__ out, int count, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * half) return;
+    const int r = i / half, j = i - r * half;
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);     // ln(10000)
+    const float a = values[r] * freq;
+    out[(int64_t)r * dim + j] = cosf(a);                 // flip_sin_to_cos=True: [cos | sin]
+    out[(int64_t)r * dim + half + j] = sinf(a);
+}
+
+// ------------------------------------------------------------------------------ small-M linear
+// one wave per output column; the M (<=16) input rows are tiny and L1/L2 resident
+template <int MAXM>
+__global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ in, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ add,
+                                                           float* __restrict__ out, int M, int N, int K, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+    const int nvec = K >> 3;
+    for (int v = lane; v < nvec; v += 64) {
+        const uint4 raw = *(const uint4*)(W + (int64_t)n * K + v * 8);
+        float wf[8]; unpack8(raw, wf);
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            if (m < M) {
+                const float4 x0 = *(const float4*)(in + (int64_t)m * K + v * 8);
+                const float4 x1 = *(const float4*)(in + (int64_t)m * K + v * 8 + 4);
+                float xf[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                if (act_in) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[j] = silu_f(xf[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m] += xf[j] * wf[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o);
+    }
+    if (lane == 0) {
+        for (int m = 0; m < M; ++m) {
+            float y = acc[m] + (bias ? bias[n] : 0.f) + (add ? add[(int64_t)m * N + n] : 0.f);
+            if (act_out) y = silu_f(y);
+            out[(int64_t)m * N + n] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ conv_in (fp32 VALU)
+// thread = one output pixel x 8 consecutive output channels; weights fp32 OHWI [Cout][3][3][Cin]
+template <int CIN>
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                      int B, int H, int W, int Cout) {
+    const int ncg = Cout >> 3;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t npix = (int64_t)B * H * W;
+    if (gid >= npix * ncg) return;
+    const int64_t pix = gid / ncg; const int cg = (int)(gid - pix * ncg);
+    const int b = (int)(pix / ((int64_t)H * W)); const int rem = (int)(pix - (int64_t)b * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    float patch[9 * CIN];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+                patch[(ky * 3 + kx) * CIN + ci] = ok ? x[(((int64_t)b * CIN + ci) * H + iy) * W + ix] : 0.f;
+        }
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = cg * 8 + j;
+        float a = bias ? bias[co] : 0.f;
+        const float* wr = w + (int64_t)co * 9 * CIN;
+#pragma unroll
+        for (int k = 0; k < 9 * CIN; ++k) a += patch[k] * wr[k];
+        o[j] = a;
+    }
+    *(uint4*)(y + pix * Cout + cg * 8) = pack8(o);
+}
+
+// ------------------------------------------------------------------------------ conv_out (MFMA)
+// wave = 16 output pixels x (<=16 padded) output channels; K = 9*Cin streamed straight from global
+// (A fragment = 16 B of one pixel's channels per lane, W fragment = 16 B of one filter row per lane).
+__global__ void __launch_bounds__(256) conv_out_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int B, int H, int W, int Cin, int Cout) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t pbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (pbase >= npix) return;
+    int64_t pix = pbase + fr; if (pix > npix - 1) pix = npix - 1;
+    const int b = (int)(pix / ((int64_t)H * W)); const int rem = (int)(pix - (int64_t)b * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    const int co = fr < Cout ? fr : Cout - 1;                 // padded filter rows replicate a real one
+    const bf16_t* wrow = w + (int64_t)co * 9 * Cin;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const frag_ab zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const bf16_t* src = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin;
+        for (int c = 0; c < Cin; c += 32) {
+            frag_ab a = *(const frag_ab*)(src + c + fg * 8);
+            if (!ok) a = zero;
+            const frag_ab wf = *(const frag_ab*)(wrow + tap * Cin + c + fg * 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf, acc, 0, 0, 0);   // D[pixel][cout]
+        }
+    }
+    // lane holds pixels pbase + 4*fg + r for output channel fr
+    if (fr < Cout) {
+        const float bv = bias ? bias[fr] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t pp = pbase + fg * 4 + r;
+            if (pp < npix) {
+                const int bb = (int)(pp / ((int64_t)H * W)); const int64_t rr = pp - (int64_t)bb * H * W;
+                y[((int64_t)bb * Cout + fr) * H * W + rr] = acc[r] + bv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tmix_groupnorm_ws_chunks(int64_t HW) { return gn_chunks(HW); }
+
+extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
+                                   const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                                   void* stream) {
+    if (!X1 || !Y || !gamma || !beta || !ws) TMIX_FAIL(TMIX_EINVAL, "groupnorm: null pointer");
+    if (C2 > 0 && !X2) TMIX_FAIL(TMIX_EINVAL, "groupnorm: C2 > 0 but X2 is null");
+    const int C = C1 + C2;
+    if (B <= 0 || HW <= 0 || C <= 0) TMIX_FAIL(TMIX_ESHAPE, "groupnorm: empty problem");
+    if ((C1 % 8) || (C2 % 8) || C > GN_MAX_C || groups <= 0 || groups > 64 || (C % groups)) TMIX_FAIL(TMIX_ESHAPE, "groupnorm: C1=%d C2=%d groups=%d unsupported", C1, C2, groups);
+    if (!aligned16(X1) || (X2 && !aligned16(X2)) || !aligned16(Y)) TMIX_FAIL(TMIX_EALIGN, "groupnorm: pointers must be 16-byte aligned");
+    const int chunks = gn_chunks(HW);
+    hipStream_t st = (hipStream_t)stream;
+    gn_stats_kernel<<<dim3(chunks, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, ws, HW, groups, chunks);
+    TMIX_LAUNCH_CHECK();
+    int64_t nb = (HW * (C / 8) + 2047) / 2048; if (nb < 1) nb = 1; if (nb > 512) nb = 512;
+    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, gamma, beta, ws, HW, groups, chunks, eps, silu);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta, int64_t rows, int C,
+                              float eps, void* stream) {
+    if (!X || !Y || !gamma || !beta) TMIX_FAIL(TMIX_EINVAL, "layernorm: null pointer");
+    if (rows <= 0 || C <= 0) TMIX_FAIL(TMIX_ESHAPE, "layernorm: empty problem");
+    if ((C % 8) || C > 2048) TMIX_FAIL(TMIX_ESHAPE, "layernorm: C=%d must be a multiple of 8 and <= 2048", C);
+    if (!aligned16(X) || !aligned16(Y) || !aligned16(gamma) || !aligned16(beta)) TMIX_FAIL(TMIX_EALIGN, "layernorm: pointers must be 16-byte aligned");
+    layernorm_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>((const bf16_t*)X, (bf16_t*)Y, gamma, beta, rows, C, eps);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_concat_channels(const void* X1, int C1, const void* X2, int C2, void* Y, int64_t rows, void* stream) {
+    if (!X1 || !X2 || !Y) TMIX_FAIL(TMIX_EINVAL, "concat: null pointer");
+    if (rows <= 0 || C1 <= 0 || C2 <= 0 || (C1 % 8) || (C2 % 8)) TMIX_FAIL(TMIX_ESHAPE, "concat: rows=%lld C1=%d C2=%d unsupported", (long long)rows, C1, C2);
+    if (!aligned16(X1) || !aligned16(X2) || !aligned16(Y)) TMIX_FAIL(TMIX_EALIGN, "concat: pointers must be 16-byte aligned");
+    int64_t nb = (rows * ((C1 + C2) / 8) + 255) / 256; if (nb > 4096) nb = 4096;
+    concat_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const uint4*)X1, C1 / 8, (const uint4*)X2, C2 / 8, (uint4*)Y, rows);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_timestep_embedding(const float* values, float* out, int count, int dim, void* stream) {
+    if (!values || !out) TMIX_FAIL(TMIX_EINVAL, "timestep_embedding: null pointer");
+    if (count <= 0 || dim <= 0 || (dim & 1)) TMIX_FAIL(TMIX_ESHAPE, "timestep_embedding: count=%d dim=%d", count, dim);
+    const int n = count * (dim / 2);
+    timestep_embedding_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(values, out, count, dim);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_linear_small(const float* in, const void* W, const float* bias, const float* add, float* out,
+                                 int M, int N, int K, int act_in, int act_out, void* stream) {
+    if (!in || !W || !out) TMIX_FAIL(TMIX_EINVAL, "linear_small: null pointer");
+    if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 8)) TMIX_FAIL(TMIX_ESHAPE, "linear_small: M=%d (1..16) N=%d K=%d (K %% 8 == 0)", M, N, K);
+    if (!aligned16(in) || !aligned16(W)) TMIX_FAIL(TMIX_EALIGN, "linear_small: in/W must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out);
+    else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
+                            int B, int Cin, int H, int W, int Cout, void* stream) {
+    if (!x_nchw || !w_ohwi || !y_nhwc) TMIX_FAIL(TMIX_EINVAL, "conv_in: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8)) TMIX_FAIL(TMIX_ESHAPE, "conv_in: bad shape");
+    if (!aligned16(y_nhwc)) TMIX_FAIL(TMIX_EALIGN, "conv_in: output must be 16-byte aligned");
+    const int64_t n = (int64_t)B * H * W * (Cout / 8);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 4)      conv_in_kernel<4><<<nb, 256, 0, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout);
+    else if (Cin == 8) conv_in_kernel<8><<<nb, 256, 0, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout);
+    else TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (4 or 8 supported)", Cin);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_conv_out(const void* x_nhwc, const void* w_ohwi, const float* bias, float* y_nchw,
+                             int B, int Cin, int H, int W, int Cout, void* stream) {
+    if (!x_nhwc || !w_ohwi || !y_nchw) TMIX_FAIL(TMIX_EINVAL, "conv_out: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 16 || (Cin % 32)) TMIX_FAIL(TMIX_ESHAPE, "conv_out: Cin=%d (%%32) Cout=%d (<=16)", Cin, Cout);
+    if (!aligned16(x_nhwc) || !aligned16(w_ohwi)) TMIX_FAIL(TMIX_EALIGN, "conv_out: pointers must be 16-byte aligned");
+    const int64_t npix = (int64_t)B * H * W;
+    const unsigned nb = (unsigned)((npix + 63) / 64);
+    conv_out_kernel<<<nb, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x_nhwc, (const bf16_t*)w_ohwi, bias, y_nchw, B, H, W, Cin, Cout);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}

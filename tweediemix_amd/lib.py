@@ -1,0 +1,92 @@
+"""ctypes binding of libtmix_hip.so (the C ABI declared in include/tmix.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtmix_hip.so")
+
+OK, EINVAL, ESHAPE, EARCH, EALIGN = 0, -1, -2, -3, -4
+F32, F16, BF16 = 0, 1, 2
+STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
+EPI_NONE, EPI_GEGLU = 0, 1
+CONV_S1, CONV_S2, CONV_UP2 = 0, 1, 2
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    """mirror of tmix_gemm_desc"""
+    _fields_ = [("A", vp), ("lda", i64), ("strideA", i64),
+                ("W", vp), ("ldw", i64), ("strideW", i64),
+                ("C", vp), ("ldc", i64), ("strideC", i64),
+                ("bias", vp), ("strideBias", i64),
+                ("residual", vp), ("ldr", i64), ("strideR", i64),
+                ("rowgroup_bias", vp), ("rows_per_group", i32),
+                ("Ct", vp), ("ldct", i64), ("strideCt", i64),
+                ("n_trans_begin", i32),
+                ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+                ("epilogue", i32)]
+
+
+class ConvDesc(C.Structure):
+    """mirror of tmix_conv_desc"""
+    _fields_ = [("X", vp), ("Wt", vp), ("Y", vp), ("bias", vp), ("batch_bias", vp), ("residual", vp),
+                ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("mode", i32)]
+
+
+SIGNATURES = {
+    "tmix_version": (C.c_int, []),
+    "tmix_last_error_string": (C.c_char_p, []),
+    "tmix_check_device": (C.c_int, []),
+    "tmix_fused_tweedie_step": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, i64, C.c_int,
+                                          f32, f32, f32, f32, f32, C.c_int, vp]),
+    "tmix_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tmix_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "tmix_conv_in": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tmix_conv_out": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tmix_attn_fwd": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,
+                                C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
+    "tmix_groupnorm_ws_chunks": (C.c_int, [i64]),
+    "tmix_groupnorm_nhwc": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, C.c_int, f32,
+                                      C.c_int, vp]),
+    "tmix_layernorm": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, f32, vp]),
+    "tmix_concat_channels": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, i64, vp]),
+    "tmix_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "tmix_linear_small": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+}
+
+_lib = None
+
+
+class TmixError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libtmix_hip.so and attach prototypes.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+                          f"or make -C tweediemix_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI and the header diverge
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tmix_version() != 100:
+        raise ImportError(f"libtmix_hip.so ABI version {lib.tmix_version()} != 100")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().tmix_last_error_string().decode("utf-8", "replace")
+        raise TmixError(f"{what} failed with code {rc}: {msg}")

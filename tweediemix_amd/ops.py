@@ -1,0 +1,254 @@
+"""Thin torch-tensor wrappers over the C ABI (include/tmix.h).
+
+PyTorch is plumbing only: device memory (data_ptr) and the current HIP stream.  Every wrapper
+validates on the C side and raises TmixError on failure; there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.TmixError("tweediemix_amd ops need device tensors (no CPU fallback exists)")
+
+
+_EPS_DT = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
+
+
+def step_coeffs(at, at_next):
+    """fp32 sqrt(at), sqrt(1-at), sqrt(at'), sqrt(1-at') exactly as the fp32 reference computes them."""
+    at, an = np.float32(at), np.float32(at_next)
+    one = np.float32(1)
+    return (float(np.sqrt(at)), float(np.sqrt(one - at)), float(np.sqrt(an)), float(np.sqrt(one - an)))
+
+
+def fused_tweedie_step(x, eps, masks, mode, K, g, at, at_next, is_last=False, out_x=None, out_x0=None):
+    """x [1,C,h,w] fp32; eps [rows,C,h,w] f32|f16|bf16; masks [K,1,h,w] fp32 (FUSION).  Returns out_x."""
+    _need_cuda(x, eps, masks)
+    lib = L.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous()
+    Cc, h, w = x.shape[-3], x.shape[-2], x.shape[-1]
+    rows = eps.shape[0]
+    need = {L.STEP_FUSION: K + 1, L.STEP_PLAIN: 2, L.STEP_RESAMPLE: K + 1}[mode]
+    if rows < need:
+        raise L.TmixError(f"tweedie step mode {mode} needs {need} eps rows, got {rows}")
+    if mode == L.STEP_FUSION:
+        assert masks is not None and masks.dtype == torch.float32 and masks.is_contiguous() and masks.shape[0] == K
+        assert masks.numel() == K * h * w
+    if out_x is None:
+        out_x = torch.empty_like(x)
+    sa, s1, san, s1n = step_coeffs(at, at_next)
+    L.check(lib.tmix_fused_tweedie_step(_p(x), _p(eps), _EPS_DT[eps.dtype], _p(masks), _p(out_x), _p(out_x0),
+                                        K, Cc, h * w, mode, float(g), sa, s1, san, s1n, int(bool(is_last)),
+                                        _stream()), "tmix_fused_tweedie_step")
+    return out_x
+
+
+def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows_per_group=0, geglu=False,
+                   out_t=None, n_trans_begin=-1):
+    """a [batch?,M,K] bf16 (last dim contiguous), w [batch?,N,K] bf16, out [batch?,M,N'] bf16."""
+    a3 = a if a.dim() == 3 else a.unsqueeze(0)
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    batch, M, K = a3.shape
+    N = w3.shape[1]
+    assert a3.dtype == BF16 and w3.dtype == BF16 and a3.stride(2) == 1 and w3.stride(2) == 1 and w3.shape[2] == K
+    d = L.GemmDesc()
+    d.A, d.lda, d.strideA = a3.data_ptr(), a3.stride(1), (a3.stride(0) if batch > 1 else 0)
+    d.W, d.ldw, d.strideW = w3.data_ptr(), w3.stride(1), (w3.stride(0) if w3.shape[0] > 1 else 0)
+    assert w3.shape[0] in (1, batch)
+    if out is not None:
+        o3 = out if out.dim() == 3 else out.unsqueeze(0)
+        assert o3.dtype == BF16 and o3.stride(2) == 1
+        d.C, d.ldc, d.strideC = o3.data_ptr(), o3.stride(1), (o3.stride(0) if batch > 1 else 0)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.stride(-1) == 1
+        d.bias = bias.data_ptr()
+        d.strideBias = bias.stride(0) if (bias.dim() == 2 and bias.shape[0] > 1) else 0
+    if residual is not None:
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        assert r3.dtype == BF16 and r3.stride(2) == 1
+        d.residual, d.ldr, d.strideR = r3.data_ptr(), r3.stride(1), (r3.stride(0) if batch > 1 else 0)
+    if rowgroup_bias is not None:
+        assert rowgroup_bias.dtype == torch.float32 and rowgroup_bias.is_contiguous()
+        d.rowgroup_bias, d.rows_per_group = rowgroup_bias.data_ptr(), rows_per_group
+    d.n_trans_begin = -1
+    if out_t is not None:
+        t3 = out_t if out_t.dim() == 3 else out_t.unsqueeze(0)
+        assert t3.dtype == BF16 and t3.stride(2) == 1
+        d.Ct, d.ldct, d.strideCt = t3.data_ptr(), t3.stride(1), (t3.stride(0) if batch > 1 else 0)
+        d.n_trans_begin = n_trans_begin
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.epilogue = L.EPI_GEGLU if geglu else L.EPI_NONE
+    return d
+
+
+def gemm(a, w, out=None, **kw):
+    """out = epi(a @ w^T).  Allocates out ([.., M, N] or [.., M, N/2] for GEGLU) when not given."""
+    _need_cuda(a, w)
+    lib = L.load()
+    if out is None and not (kw.get("out_t") is not None and kw.get("n_trans_begin", -1) == 0):
+        N = w.shape[-2]
+        No = N // 2 if kw.get("geglu") else N
+        if kw.get("out_t") is not None:
+            No = kw["n_trans_begin"]
+        out = torch.empty(*a.shape[:-1], No, device=a.device, dtype=BF16)
+    d = make_gemm_desc(a, w, out, **kw)
+    L.check(lib.tmix_gemm_bf16(C.byref(d), _stream()), "tmix_gemm_bf16")
+    return out
+
+
+def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1):
+    """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert x.dtype == BF16 and w.dtype == BF16 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    assert tuple(w.shape) == (Cout, 3, 3, Cin)
+    d = L.ConvDesc()
+    d.X, d.Wt, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias, d.batch_bias, d.residual = _p(bias), _p(batch_bias), _p(residual)
+    d.B, d.H, d.W, d.Cin, d.Cout, d.mode = B, H, W, Cin, Cout, mode
+    return d
+
+
+def conv_out_hw(H, W, mode):
+    return (H // 2, W // 2) if mode == L.CONV_S2 else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
+
+
+def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None):
+    _need_cuda(x, w)
+    lib = L.load()
+    B, H, W, _ = x.shape
+    Ho, Wo = conv_out_hw(H, W, mode)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, w.shape[0], device=x.device, dtype=BF16)
+    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode)
+    L.check(lib.tmix_conv3x3_nhwc(C.byref(d), _stream()), "tmix_conv3x3_nhwc")
+    return out
+
+
+def conv_in(x_nchw, w_ohwi, bias, out=None):
+    """fp32 NCHW [B,Cin,H,W] -> bf16 NHWC [B,H,W,Cout]; w fp32 [Cout,3,3,Cin]."""
+    _need_cuda(x_nchw, w_ohwi)
+    lib = L.load()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w_ohwi.shape[0]
+    assert x_nchw.dtype == torch.float32 and w_ohwi.dtype == torch.float32 and x_nchw.is_contiguous() and w_ohwi.is_contiguous()
+    if out is None:
+        out = torch.empty(B, H, W, Cout, device=x_nchw.device, dtype=BF16)
+    L.check(lib.tmix_conv_in(_p(x_nchw), _p(w_ohwi), _p(bias), _p(out), B, Cin, H, W, Cout, _stream()), "tmix_conv_in")
+    return out
+
+
+def conv_out(x_nhwc, w_ohwi, bias, out=None):
+    """bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,Cout,H,W]; w bf16 [Cout,3,3,Cin]."""
+    _need_cuda(x_nhwc, w_ohwi)
+    lib = L.load()
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_ohwi.shape[0]
+    assert x_nhwc.dtype == BF16 and w_ohwi.dtype == BF16 and x_nhwc.is_contiguous() and w_ohwi.is_contiguous()
+    if out is None:
+        out = torch.empty(B, Cout, H, W, device=x_nhwc.device, dtype=torch.float32)
+    L.check(lib.tmix_conv_out(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(out), B, Cin, H, W, Cout, _stream()), "tmix_conv_out")
+    return out
+
+
+def attention(q, k, vt, H, Skv, scale, out=None):
+    """q [B,Sq,>=H*64] bf16 (row stride free), k [B,>=Skv,..] bf16, vt [B,H*64,ldvt] bf16 (V transposed)."""
+    _need_cuda(q, k, vt)
+    lib = L.load()
+    B, Sq = q.shape[0], q.shape[1]
+    assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    if out is None:
+        out = torch.empty(B, Sq, H * 64, device=q.device, dtype=BF16)
+    L.check(lib.tmix_attn_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
+                              _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
+                              B, H, Sq, Skv, float(scale), _stream()), "tmix_attn_fwd")
+    return out
+
+
+def groupnorm_ws(B, HW, groups, device):
+    chunks = L.load().tmix_groupnorm_ws_chunks(HW)
+    return torch.empty(B * chunks * groups * 2, device=device, dtype=torch.float32)
+
+
+def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=None, ws=None):
+    """x1 [B,HW,C1] (+ optional x2 [B,HW,C2], normalised as channel-concat) bf16 NHWC."""
+    _need_cuda(x1, gamma, beta)
+    lib = L.load()
+    B, HW, C1 = x1.shape[0], x1.numel() // (x1.shape[0] * x1.shape[-1]), x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    assert x1.is_contiguous() and (x2 is None or x2.is_contiguous()) and gamma.dtype == torch.float32
+    if out is None:
+        out = torch.empty(*x1.shape[:-1], C1 + C2, device=x1.device, dtype=BF16)
+    if ws is None:
+        ws = groupnorm_ws(B, HW, groups, x1.device)
+    L.check(lib.tmix_groupnorm_nhwc(_p(x1), C1, _p(x2), C2, _p(out), _p(gamma), _p(beta), _p(ws), B, HW, groups,
+                                    float(eps), int(bool(silu)), _stream()), "tmix_groupnorm_nhwc")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _need_cuda(x, gamma, beta)
+    lib = L.load()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    assert x.is_contiguous() and x.dtype == BF16 and gamma.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.tmix_layernorm(_p(x), _p(out), _p(gamma), _p(beta), rows, Cc, float(eps), _stream()), "tmix_layernorm")
+    return out
+
+
+def concat_channels(x1, x2, out=None):
+    _need_cuda(x1, x2)
+    lib = L.load()
+    C1, C2 = x1.shape[-1], x2.shape[-1]
+    rows = x1.numel() // C1
+    assert x1.is_contiguous() and x2.is_contiguous() and x1.dtype == BF16 and x2.dtype == BF16
+    if out is None:
+        out = torch.empty(*x1.shape[:-1], C1 + C2, device=x1.device, dtype=BF16)
+    L.check(lib.tmix_concat_channels(_p(x1), C1, _p(x2), C2, _p(out), rows, _stream()), "tmix_concat_channels")
+    return out
+
+
+def timestep_embedding(values, dim, out=None):
+    _need_cuda(values)
+    lib = L.load()
+    assert values.dtype == torch.float32 and values.is_contiguous()
+    n = values.numel()
+    if out is None:
+        out = torch.empty(n, dim, device=values.device, dtype=torch.float32)
+    L.check(lib.tmix_timestep_embedding(_p(values), _p(out), n, dim, _stream()), "tmix_timestep_embedding")
+    return out
+
+
+def linear_small(x, w, bias=None, add=None, act_in=False, act_out=False, out=None):
+    """x [M<=16,K] fp32, w [N,K] bf16 -> [M,N] fp32."""
+    _need_cuda(x, w)
+    lib = L.load()
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype == BF16 and w.is_contiguous() and w.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    L.check(lib.tmix_linear_small(_p(x), _p(w), _p(bias), _p(add), _p(out), M, N, K, int(bool(act_in)),
+                                  int(bool(act_out)), _stream()), "tmix_linear_small")
+    return out
