@@ -39,10 +39,9 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
     const int64_t ppc = (HW + chunks - 1) / chunks;
     const int64_t p0 = (int64_t)ch * ppc;
     int64_t p1 = p0 + ppc; if (p1 > HW) p1 = HW;
-    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
-    // fixed vector column per thread so the 8 per-channel sums stay in registers across pixels
-    const int plane = nvec <= 256 ? 256 / nvec : 1;          // pixel lanes per block
+    // fixed vector column per thread so the 8 per-channel sums stay in registers across pixels;
+    // partials land in LDS at [pixel lane][channel] and are reduced in a fixed order (deterministic).
+    const int plane = nvec <= 256 ? 256 / nvec : 1;          // pixel lanes per block; plane * C <= 2048
     for (int v0 = 0; v0 < nvec; v0 += 256) {
         const int v = v0 + (nvec <= 256 ? tid % nvec : tid);
         const int pl = nvec <= 256 ? tid / nvec : 0;
@@ -59,13 +58,14 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
                 for (int j = 0; j < 8; ++j) { a[j] += f[j]; q[j] += f[j] * f[j]; }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&s_sum[c0 + j], a[j]); atomicAdd(&s_sq[c0 + j], q[j]); }
+            for (int j = 0; j < 8; ++j) { s_sum[pl * C + c0 + j] = a[j]; s_sq[pl * C + c0 + j] = q[j]; }
         }
     }
     __syncthreads();
     if (tid < groups) {
         float s = 0.f, q = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += s_sum[c]; q += s_sq[c]; }
+        for (int pl = 0; pl < plane; ++pl)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += s_sum[pl * C + c]; q += s_sq[pl * C + c]; }
         float* o = ws + (((int64_t)b * chunks + ch) * groups + tid) * 2;
         o[0] = s; o[1] = q;
     }

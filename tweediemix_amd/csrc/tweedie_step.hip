@@ -13,8 +13,13 @@ template <> struct EpsT<TMIX_BF16> { typedef bf16_t T; static __device__ __force
 
 // rounding point of the reference's autocast path (only when eps is fp16)
 template <int DT> __device__ __forceinline__ float rnd(float v) {
-    if constexpr (DT == TMIX_F16) return __half2float(__float2half_rn(v));
-    else return v;
+    if constexpr (DT == TMIX_F16) {
+        // torch evaluates fp16 elementwise ops in fp32 and rounds the fp32 RESULT to fp16 (two roundings).
+        // The empty asm makes the fp32 value opaque so LLVM cannot fold mul+convert into the single-rounding
+        // v_fma_mixlo_f16, which differs from the reference on near-ties.
+        asm volatile("" : "+v"(v));
+        return __half2float(__float2half_rn(v));
+    } else return v;
 }
 
 template <int DT> __device__ __forceinline__ float cfg(float eu, float ec, float g) {

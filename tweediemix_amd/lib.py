@@ -72,6 +72,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: libtmix_hip.so needs libamdhip64.so.7 and has to bind to the SAME
+    # HIP runtime instance torch uses (streams and device pointers are shared); torch ships its own copy.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
                           f"or make -C tweediemix_amd/csrc). There is no CPU fallback.")

@@ -1,0 +1,226 @@
+"""Tweedie-mix sampler: host-side mirror of the reference's `Tweediemix` hot path.
+
+Same method names, argument meaning and step semantics as fusion_generation/fusion_sampling.py
+(`alpha` :305-307, `denoise_step` :309-474, `init_fusion` :476-483, `run_fusion` :485-489,
+`sample_loop` :490-530) and fusion_sampling_lora.py (`--t_stop` window :324,378,476-492), with
+
+* phase decisions and alpha tables on the host as plain ints/floats (the reference syncs the device
+  several times per step through `.item()` and CPU-tensor indexing),
+* one UNet launch plan per call kind (fusion / start / plain), each with its own cross-attention K/V
+  cache, optionally captured into a hipGraph,
+* CFG + Tweedie + blend + DDIM done by ONE kernel (tmix_fused_tweedie_step).
+
+Out of scope here (SURVEY 8f "next" rows): the HF checkpoint/tokenizer/text-encoder loading of
+`Tweediemix.__init__`, the VAE decode at the end of `sample_loop`, and the segmentation side-car
+process; their inputs/outputs (prompt embeddings, masks) are constructor arguments instead.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from . import lib as L
+from . import ops
+from .schedule import Schedule
+from .unet import KVCache, UNetPlan, UNetWeights
+
+F32 = torch.float32
+
+
+def seed_everything(seed: int):
+    """utils_custom.py:10-14"""
+    import random
+
+    import numpy as np
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+DEFAULTS = dict(seed=182, guidance_scale=9.0, n_timesteps=50, t_cond=0.4, t_stop=0.9, resampling_steps=10,
+                jumping_steps=5, resolution_h=1024, resolution_w=1024, crops_coords_top_left_h=0,
+                crops_coords_top_left_w=0)      # argparse defaults of fusion_sampling.py:534-585
+
+
+def make_config(**kw):
+    d = dict(DEFAULTS)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+class Tweediemix:
+    """config: namespace with the reference's flag names (guidance_scale, n_timesteps, t_cond,
+    [t_stop], resampling_steps, jumping_steps, resolution_h/w, crops_coords_top_left_h/w, seed).
+
+    weights           UNetWeights (base UNet + K concept weight sets, kind 'custom' | 'lora' | 'none')
+    text_embeds       ([K+2,77,D], [K+2,P])  rows: 0 uncond, 1 multi-concept prompt, 2.. per-concept prompts
+    text_embeds_single([K,77,D],   [K,P])    rows: 0 uncond, 1.. single-concept prompts without modifier tokens
+    mask_provider     callable(x0_preview [1,4,h,w]) -> masks [K,1,h,w] fp32 (stands in for decode +
+                      run_expand.py + preprocess_mask at fusion_sampling.py:453-469)
+    lora              True selects the fusion_sampling_lora.py window semantics (needs config.t_stop)
+    strict_reference  keep the hooks' hard-coded `batch == 4` routing test (utils_custom.py:62)
+    """
+
+    def __init__(self, config, weights: UNetWeights, text_embeds, text_embeds_single, mask_provider,
+                 concept_num: int, lora: bool = False, strict_reference: bool = True, use_graphs: bool = False):
+        self.config = config
+        self.W = weights
+        self.device = weights.device
+        self.concept_num = int(concept_num)
+        self.lora = bool(lora)
+        self.strict_reference = strict_reference
+        self.use_graphs = use_graphs
+        self.text_embeds = text_embeds
+        self.text_embeds_single = text_embeds_single
+        self.mask_provider = mask_provider
+        self.masks = None
+        self.scheduler = Schedule(config.n_timesteps)
+        self.skip = self.scheduler.skip
+        self.final_alpha_cumprod = self.scheduler.final_alpha_cumprod
+        self.h, self.w = config.resolution_h // 8, config.resolution_w // 8
+        # compute_time_ids, fusion_sampling.py:70-78
+        self.add_time_ids = torch.tensor([[config.resolution_h, config.resolution_w, config.crops_coords_top_left_h,
+                                           config.crops_coords_top_left_w, config.resolution_h, config.resolution_w]],
+                                         dtype=F32)
+        self.plans = {}
+        self.graphs = {}
+        self.unet_calls = []          # (kind, B, t) trace, for tests / accounting
+        self.preview_x0 = None
+        self._bufs = [torch.empty(1, 4, self.h, self.w, device=self.device, dtype=F32) for _ in range(3)]
+
+    # ------------------------------------------------------------------ schedule
+    def alpha(self, t):
+        return self.scheduler.alpha(int(t))
+
+    # ------------------------------------------------------------------ plans
+    def _routes(self, B):
+        return B == 4 if self.strict_reference else B == self.concept_num + 1
+
+    def _build_plan(self, kind):
+        K = self.concept_num
+        te, tp = self.text_embeds
+        if kind in ("fusion", "fusion_base"):
+            ehs = torch.cat([te[0:1], te[2:2 + K]])
+            pooled = torch.cat([tp[0:1], tp[2:2 + K]])
+            routed = kind == "fusion" and self._routes(K + 1) and self.W.kind != "none"
+            wsel = list(range(K + 1)) if routed else [0] * (K + 1)
+        elif kind == "start":
+            ts_, tps = self.text_embeds_single
+            ehs = torch.cat([te[0:1], te[1:2], ts_[1:K]])
+            pooled = torch.cat([tp[0:1], tp[1:2], tps[1:K]])
+            routed, wsel = False, [0] * (K + 1)
+        elif kind == "plain":
+            ehs, pooled, routed, wsel = te[0:2], tp[0:2], False, [0, 0]
+        else:
+            raise ValueError(kind)
+        B = ehs.shape[0]
+        kv = KVCache(self.W, ehs, wsel)
+        return UNetPlan(self.W, B, self.h, self.w, kv, pooled, self.add_time_ids.repeat(B, 1), routed=routed)
+
+    def plan(self, kind):
+        if kind not in self.plans:
+            self.plans[kind] = self._build_plan(kind)
+        return self.plans[kind]
+
+    def _unet(self, kind, x, t):
+        """eps [B,4,h,w] fp32 for the call kind's prompt rows; x is broadcast over the batch."""
+        p = self.plan(kind)
+        self.unet_calls.append((kind, p.B, int(t)))
+        p.latent.copy_(x.expand(p.B, -1, -1, -1))
+        p.t_dev.fill_(float(t))
+        if self.use_graphs:
+            g = self.graphs.get(kind)
+            if g is None:
+                p.run()                                   # warm-up (sets kernel attributes) outside capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    p.run()
+                self.graphs[kind] = g
+            g.replay()
+        else:
+            p.run()
+        return p.eps
+
+    # ------------------------------------------------------------------ phases
+    def init_fusion(self, t_cond, t_stop=None):
+        ts = self.scheduler.timesteps
+        if self.lora:
+            assert t_stop is not None
+            self.t_cond = ts[t_cond:t_stop] if t_cond >= 0 else []       # fusion_sampling_lora.py:477
+            self.t_stop_cur = ts[t_stop]
+        else:
+            self.t_cond = ts[t_cond:] if t_cond >= 0 else []             # fusion_sampling.py:477
+            self.t_stop_cur = None
+        self._window = set(self.t_cond)
+        self.t_cond_prev = ts[t_cond - 1]
+        self.t_cond_cur = ts[t_cond]
+        self.start_t = ts[0]
+
+    def _in_fusion(self, t):
+        if self.lora:
+            return t <= self.t_cond_cur and t >= self.t_stop_cur
+        return t <= self.t_cond_cur
+
+    def _step(self, x, eps, mode, at, at_next, is_last=False, out=None, out_x0=None):
+        return ops.fused_tweedie_step(x, eps, self.masks if mode == L.STEP_FUSION else None, mode, self.concept_num,
+                                      self.config.guidance_scale, at, at_next, is_last, out_x=out, out_x0=out_x0)
+
+    @torch.no_grad()
+    def denoise_step(self, x, t):
+        """x [1,4,h,w] fp32 on the device, t python int (or 0-dim tensor). Returns the next latent."""
+        t = int(t)
+        cfg = self.config
+        next_t = t - self.skip
+        at, at_next = self.alpha(t), self.alpha(next_t)
+        last = t == 1
+        x0 = self._bufs[2]
+        if self._in_fusion(t):
+            kind = "fusion" if (t in self._window) else "fusion_base"
+            eps = self._unet(kind, x, t)
+            out = self._step(x, eps, L.STEP_FUSION, at, at_next, last, out_x0=x0)
+        elif t == self.start_t:
+            eps = self._unet("start", x, t)
+            for _ in range(cfg.resampling_steps):
+                xd = self._step(x, eps, L.STEP_RESAMPLE, at, at_next, out=self._bufs[0])
+                eps_n = self._unet("plain", xd, next_t)
+                x = self._step(xd, eps_n, L.STEP_PLAIN, at_next, at, out=self._bufs[1])   # Tweedie at next_t, re-noise to t
+                eps = self._unet("start", x, t)
+            out = self._step(x, eps, L.STEP_PLAIN, at, at_next, last, out_x0=x0)
+        else:
+            eps = self._unet("plain", x, t)
+            out = self._step(x, eps, L.STEP_PLAIN, at, at_next, last, out_x0=x0)
+
+        if t == self.t_cond_prev:                       # fusion_sampling.py:431-469
+            xt, tt, x0j = out, next_t, x0
+            for _ in range(cfg.jumping_steps):
+                a_t = self.alpha(tt)
+                eps_j = self._unet("plain", xt, tt)
+                tt = tt - 150
+                x0j = torch.empty_like(out)
+                xt = self._step(xt, eps_j, L.STEP_PLAIN, a_t, self.alpha(tt), out_x0=x0j)
+            self.preview_x0 = x0j.clone()
+            self.masks = self.mask_provider(self.preview_x0).to(self.device, F32).contiguous()
+            assert self.masks.shape[0] == self.concept_num
+        return out
+
+    def run_fusion(self, x=None):
+        cfg = self.config
+        t_cond = int(cfg.n_timesteps * cfg.t_cond)
+        if self.lora:
+            self.init_fusion(t_cond, int(cfg.n_timesteps * cfg.t_stop))
+        else:
+            self.init_fusion(t_cond)
+        if x is None:      # drawn on the CPU like the reference (fusion_sampling.py:488): device-independent seeds
+            x = torch.randn(1, 4, self.h, self.w) * self.scheduler.init_noise_sigma
+        return self.sample_loop(x.to(self.device, F32))
+
+    @torch.no_grad()
+    def sample_loop(self, x):
+        """runs every scheduler timestep; returns the final latent (VAE decode is a 'next' row)."""
+        for t in self.scheduler.timesteps:
+            x = self.denoise_step(x, t).clone()
+        return x

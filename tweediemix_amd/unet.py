@@ -1,0 +1,485 @@
+"""SDXL UNet forward as a static launch plan over the C ABI (include/tmix.h).
+
+What `self.unet(latents, t, encoder_hidden_states, added_cond_kwargs)['sample']` computes at
+fusion_sampling.py:340/374/406/414/440 (diffusers UNet2DConditionModel, SDXL-base config), with the
+reference's attention hooks (utils_custom.py:53-108, utils_lora.py:55-123) folded in:
+
+* activations are NHWC bf16 ([B, H*W, C] is both the conv and the token layout: no permutes),
+* every Linear/conv is tmix_gemm_bf16 / tmix_conv3x3_nhwc with bias, time-embedding, residual and
+  GEGLU fused into the epilogue; QKV is one GEMM whose V third is stored transposed for
+  tmix_attn_fwd,
+* cross-attention K/V depend only on the prompt rows and the (per-concept) weights, so they are
+  computed ONCE per call kind (`KVCache`) instead of 75x per image; the per-row concept routing of
+  the hooks becomes "which weight set produced row b of the cache",
+* LoRA rows use merged weights W + up@down as one weight set per batch row (batched GEMM).
+
+A plan is a fixed list of (C function, argument tuple): running it is a tight loop with no tensor
+allocation, so it can be captured into a hipGraph (torch.cuda.graphs) and replayed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import lib as L
+from . import ops
+from .weights import interleave_geglu
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: tuple = (320, 640, 1280)
+    layers_per_block: int = 2
+    transformer_layers: tuple = (0, 2, 10)
+    head_dim: int = 64
+    cross_dim: int = 2048
+    pooled_dim: int = 1280
+    addition_time_embed_dim: int = 256
+    norm_groups: int = 32
+
+    @property
+    def time_embed_dim(self):
+        return self.block_out_channels[0] * 4
+
+    @property
+    def add_in_dim(self):
+        return self.pooled_dim + 6 * self.addition_time_embed_dim
+
+
+SDXL = UNetConfig()
+TINY = UNetConfig(block_out_channels=(64, 128, 256), transformer_layers=(0, 1, 2), cross_dim=128,
+                  pooled_dim=64, addition_time_embed_dim=32)
+
+
+def transformer_sites(cfg: UNetConfig):
+    """[(t2d prefix, channels, n_layers)] in forward order (down, mid, up)."""
+    out = []
+    ch = cfg.block_out_channels
+    nb = len(ch)
+    for bi in range(nb):
+        for j in range(cfg.layers_per_block):
+            if cfg.transformer_layers[bi]:
+                out.append((f"down_blocks.{bi}.attentions.{j}", ch[bi], cfg.transformer_layers[bi]))
+    out.append(("mid_block.attentions.0", ch[-1], cfg.transformer_layers[-1]))
+    for ui in range(nb):
+        bi = nb - 1 - ui
+        for j in range(cfg.layers_per_block + 1):
+            if cfg.transformer_layers[bi]:
+                out.append((f"up_blocks.{ui}.attentions.{j}", ch[bi], cfg.transformer_layers[bi]))
+    return out
+
+
+def attention_blocks(cfg: UNetConfig):
+    """every '<t2d>.transformer_blocks.i' prefix with its width, forward order."""
+    return [(f"{p}.transformer_blocks.{i}", c) for p, c, n in transformer_sites(cfg) for i in range(n)]
+
+
+# =====================================================================================
+class UNetWeights:
+    """Device-resident weights in kernel layouts, built from a diffusers-keyed state dict.
+
+    concepts: None | ('custom', [sd_i]) with keys '<tb>.attn2.to_k.weight' / '.to_v.weight'
+              (fusion_sampling.py:203-210) | ('lora', [sd_i]) with keys
+              '<tb>.attnN.processor.to_{q,k,v,out}_lora.{down,up}.weight' (fusion_sampling_lora.py:207-210).
+    """
+
+    def __init__(self, cfg: UNetConfig, sd: dict, device="cuda", concepts=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.kind = concepts[0] if concepts else "none"
+        self.K = len(concepts[1]) if concepts else 0
+        dev = self.device
+        t = {}
+
+        def g(name):
+            return sd[name].to(dev)
+
+        def bf(x):
+            return x.to(dev, BF16).contiguous()
+
+        def f32(x):
+            return x.to(dev, F32).contiguous()
+
+        for name, v in sd.items():
+            if name.endswith(".bias") or ".norm" in name and name.endswith(".weight") or name.startswith("conv_norm_out"):
+                t[name] = f32(v)
+        t["conv_in.weight"] = f32(g("conv_in.weight").permute(0, 2, 3, 1))
+        t["conv_out.weight"] = bf(g("conv_out.weight").permute(0, 2, 3, 1))
+        for name, v in sd.items():
+            if not name.endswith(".weight") or name in ("conv_in.weight", "conv_out.weight"):
+                continue
+            if v.dim() == 4 and v.shape[-1] == 3:
+                t[name] = bf(v.to(dev).permute(0, 2, 3, 1))
+            elif v.dim() == 4:                                   # 1x1 conv_shortcut -> Linear
+                t[name] = bf(v.to(dev).reshape(v.shape[0], v.shape[1]))
+            elif v.dim() == 2 and ".attn" not in name and ".ff.net.0.proj" not in name:
+                t[name] = bf(v)
+        lora = concepts[1] if self.kind == "lora" else None
+        custom = concepts[1] if self.kind == "custom" else None
+
+        def merged(base, key, which):
+            """[1+K, N, Kin]: row 0 base, row 1+i = W + up_i @ down_i (utils_lora.py:65-79,113-119)."""
+            rows = [base.to(dev, F32)]
+            for csd in lora:
+                dn = csd[f"{key}.processor.to_{which}_lora.down.weight"].to(dev, F32)
+                up = csd[f"{key}.processor.to_{which}_lora.up.weight"].to(dev, F32)
+                rows.append(rows[0] + up @ dn)
+            return torch.stack(rows)
+
+        for tb, _c in attention_blocks(cfg):
+            a1, a2 = tb + ".attn1", tb + ".attn2"
+            t[a1 + ".qkv"] = bf(torch.cat([g(a1 + ".to_q.weight"), g(a1 + ".to_k.weight"), g(a1 + ".to_v.weight")]))
+            t[a1 + ".out"] = bf(g(a1 + ".to_out.0.weight"))
+            t[a2 + ".q"] = bf(g(a2 + ".to_q.weight"))
+            t[a2 + ".out"] = bf(g(a2 + ".to_out.0.weight"))
+            kv_rows = [torch.cat([g(a2 + ".to_k.weight"), g(a2 + ".to_v.weight")]).to(F32)]
+            if custom is not None:                      # row 1+i: concept i's to_k / to_v (utils_custom.py:66-80)
+                for csd in custom:
+                    kv_rows.append(torch.cat([csd[a2 + ".to_k.weight"].to(dev, F32), csd[a2 + ".to_v.weight"].to(dev, F32)]))
+            if lora is not None:
+                mk = merged(g(a2 + ".to_k.weight"), a2, "k")
+                mv = merged(g(a2 + ".to_v.weight"), a2, "v")
+                kv_rows = [torch.cat([mk[i], mv[i]]) for i in range(mk.shape[0])]
+                t[a1 + ".qkv_rows"] = bf(torch.cat([merged(g(a1 + ".to_q.weight"), a1, "q"),
+                                                    merged(g(a1 + ".to_k.weight"), a1, "k"),
+                                                    merged(g(a1 + ".to_v.weight"), a1, "v")], dim=1))
+                t[a1 + ".out_rows"] = bf(merged(g(a1 + ".to_out.0.weight"), a1, "out"))
+                t[a2 + ".q_rows"] = bf(merged(g(a2 + ".to_q.weight"), a2, "q"))
+                t[a2 + ".out_rows"] = bf(merged(g(a2 + ".to_out.0.weight"), a2, "out"))
+            t[a2 + ".kv_rows"] = bf(torch.stack(kv_rows))       # [1 or 1+K, 2C, cross]
+            wi, bi = interleave_geglu(g(tb + ".ff.net.0.proj.weight"), g(tb + ".ff.net.0.proj.bias"))
+            t[tb + ".ff1"] = bf(wi)
+            t[tb + ".ff1.bias"] = f32(bi)
+        self.t = t
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+    def nbytes(self):
+        return sum(v.numel() * v.element_size() for v in self.t.values())
+
+
+# =====================================================================================
+class KVCache:
+    """Cross-attention K and V^T for one call kind: for every attn2 module, K [B,77,C] and
+    V^T [B,C,80], where batch row b was projected with weight-set wsel[b] (0 = base UNet, 1+i =
+    concept i) -- the time-invariant part of utils_custom.py:64-83 hoisted out of the loop."""
+
+    def __init__(self, W: UNetWeights, ehs: torch.Tensor, wsel):
+        cfg = W.cfg
+        B, Lk, cross = ehs.shape
+        assert cross == cfg.cross_dim and len(wsel) == B
+        ehs = ehs.to(W.device, BF16).contiguous()
+        self.B, self.Lk = B, Lk
+        self.ld = (Lk + 7) // 8 * 8
+        self.k, self.vt = {}, {}
+        idx = torch.tensor(list(wsel), device=W.device)
+        for tb, Cc in attention_blocks(cfg):
+            a2 = tb + ".attn2"
+            rows = W[a2 + ".kv_rows"]
+            wsel_w = rows[idx] if rows.shape[0] > 1 else rows[:1].expand(B, -1, -1)
+            wsel_w = wsel_w.contiguous()
+            k = torch.empty(B, Lk, Cc, device=W.device, dtype=BF16)
+            vt = torch.zeros(B, Cc, self.ld, device=W.device, dtype=BF16)
+            ops.gemm(ehs, wsel_w, out=k, out_t=vt, n_trans_begin=Cc)
+            self.k[a2], self.vt[a2] = k, vt
+        torch.cuda.synchronize()
+
+
+# =====================================================================================
+class _Arena:
+    """Size-keyed free list: the plan is a static, stream-ordered launch sequence, so a buffer released
+    at plan position i can be handed to any op planned after i."""
+
+    def __init__(self, device):
+        self.device, self.free, self.total = device, {}, 0
+
+    def get(self, *shape, dtype=BF16):
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+        lst = self.free.get(nbytes)
+        if lst:
+            buf = lst.pop()
+        else:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.total += nbytes
+        tns = buf.view(dtype)[:n].view(*shape)
+        tns._arena_buf = buf
+        return tns
+
+    def put(self, *ts):
+        for tns in ts:
+            buf = tns._arena_buf
+            self.free.setdefault(buf.numel(), []).append(buf)
+
+
+class UNetPlan:
+    """One UNet call shape: batch B, latent h x w, a KV cache (prompt rows) and a routing flag.
+
+    inputs  : self.latent [B,4,h,w] fp32, self.t_dev [B] fp32 (timestep, same value in every row)
+    output  : self.eps [B,4,h,w] fp32
+    """
+
+    def __init__(self, W: UNetWeights, B: int, h: int, w: int, kv: KVCache, pooled: torch.Tensor,
+                 time_ids: torch.Tensor, routed: bool = False):
+        self.W, self.cfg, self.B, self.h, self.w = W, W.cfg, B, h, w
+        self.kv = kv
+        self.routed = bool(routed) and W.kind == "lora" and B == W.K + 1
+        self.lib = L.load()
+        self.dev = W.device
+        self.ops = []
+        self.keep = []                      # descriptors / tensors that must outlive the plan
+        self.arena = _Arena(self.dev)
+        self.flops = 0
+        self.gemm_flops = 0
+        self.launches = {"gemm": [], "conv": [], "attn": []}
+        cfg = self.cfg
+        assert kv.B == B
+        dev = self.dev
+        self.latent = torch.zeros(B, cfg.in_channels, h, w, device=dev, dtype=F32)
+        self.t_dev = torch.zeros(B, device=dev, dtype=F32)
+        self.eps = torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
+        # static conditioning: aug_emb = add_embedding(cat[pooled, sinusoid(time_ids)])  (depends on rows only)
+        tid = ops.timestep_embedding(time_ids.to(dev, F32).reshape(-1).contiguous(), cfg.addition_time_embed_dim)
+        add_in = torch.cat([pooled.to(dev, F32), tid.reshape(B, -1)], dim=-1).contiguous()
+        hid = ops.linear_small(add_in, W["add_embedding.linear_1.weight"], W["add_embedding.linear_1.bias"], act_out=True)
+        self.aug = ops.linear_small(hid, W["add_embedding.linear_2.weight"], W["add_embedding.linear_2.bias"])
+        torch.cuda.synchronize()
+        self._gn_ws = torch.empty(B * 128 * cfg.norm_groups * 2, device=dev, dtype=F32)
+        self._vt = {}
+        self._build()
+
+    # ------------------------------------------------------------------ op emitters
+    def _emit(self, fn, *args):
+        self.ops.append((fn, args))
+
+    def _gn(self, x, Cc, HW, name, eps, silu, out=None):
+        out = out if out is not None else self.arena.get(self.B, HW, Cc)
+        W = self.W
+        self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+                   W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu))
+        return out
+
+    def _gemm(self, a, w, out, **kw):
+        d = ops.make_gemm_desc(a, w, out, **kw)
+        self.keep.append(d)
+        self._emit(self.lib.tmix_gemm_bf16, C.byref(d))
+        fl = 2 * d.M * d.N * d.K * d.batch
+        self.flops += fl
+        self.gemm_flops += fl
+        self.launches["gemm"].append((d, fl))
+        return out
+
+    def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None):
+        Ho, Wo = ops.conv_out_hw(Hh, Ww, mode)
+        out = self.arena.get(self.B, Ho * Wo, Cout)
+        d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Cin), self.W[wname + ".weight"], out.view(self.B, Ho, Wo, Cout),
+                               self.W[wname + ".bias"], batch_bias, residual, mode)
+        self.keep.append(d)
+        self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
+        fl = 2 * self.B * Ho * Wo * Cout * 9 * Cin
+        self.flops += fl
+        self.launches["conv"].append((d, fl))
+        return out
+
+    def _ln(self, x, name, rows, Cc):
+        out = self.arena.get(*x.shape)
+        self._emit(self.lib.tmix_layernorm, x.data_ptr(), out.data_ptr(), self.W[name + ".weight"].data_ptr(),
+                   self.W[name + ".bias"].data_ptr(), rows, Cc, 1e-5)
+        return out
+
+    def _attn(self, q, k, vt, out, H, Sq, Skv):
+        args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
+                vt.data_ptr(), vt.stride(1), vt.stride(0), out.data_ptr(), out.stride(1), out.stride(0),
+                self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5)
+        self._emit(self.lib.tmix_attn_fwd, *args)
+        fl = 4 * self.B * H * Sq * Skv * 64
+        self.flops += fl
+        self.launches["attn"].append((args, fl))
+        return out
+
+    def _vt_buf(self, Cc, S):
+        ld = (S + 7) // 8 * 8
+        key = (Cc, ld)
+        if key not in self._vt:               # zero-filled once: the GEMM only writes columns < S
+            self._vt[key] = torch.zeros(self.B, Cc, ld, device=self.dev, dtype=BF16)
+        return self._vt[key]
+
+    # ------------------------------------------------------------------ blocks
+    def _resnet(self, x, Ci, Co, Hh, Ww, name, emb):
+        B, W, A = self.B, self.W, self.arena
+        HW = Hh * Ww
+        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True)
+        temb = torch.empty(B, Co, device=self.dev, dtype=F32)
+        self.keep.append(temb)
+        self._emit(self.lib.tmix_linear_small, emb.data_ptr(), W[name + ".time_emb_proj.weight"].data_ptr(),
+                   W[name + ".time_emb_proj.bias"].data_ptr(), None, temb.data_ptr(), B, Co, self.cfg.time_embed_dim, 1, 0)
+        h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb)
+        A.put(h1)
+        h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
+        A.put(h2)
+        if Ci != Co:
+            sc = A.get(B, HW, Co)
+            self._gemm(x.view(B * HW, Ci), W[name + ".conv_shortcut.weight"], sc.view(B * HW, Co), bias=W[name + ".conv_shortcut.bias"])
+        else:
+            sc = x
+        out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, residual=sc)
+        A.put(h3)
+        if Ci != Co:
+            A.put(sc)
+        return out
+
+    def _proj(self, a, key, out, S, Cin, **kw):
+        """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM."""
+        W = self.W
+        if self.routed:
+            return self._gemm(a.view(self.B, S, Cin), W[key + "_rows"], out, **kw)
+        o2 = out.view(self.B * S, out.shape[-1]) if out is not None else None
+        for kk in ("residual",):
+            if kw.get(kk) is not None:
+                kw[kk] = kw[kk].view(self.B * S, kw[kk].shape[-1])
+        if kw.get("out_t") is not None:       # transposed V is per batch row -> keep the batch dimension
+            return self._gemm(a.view(self.B, S, Cin), W[key], out, **kw)
+        return self._gemm(a.view(self.B * S, Cin), W[key], o2, **kw)
+
+    def _t2d(self, x, Cc, Hh, Ww, name, n):
+        B, W, A = self.B, self.W, self.arena
+        S = Hh * Ww
+        H = Cc // self.cfg.head_dim
+        g = self._gn(x, Cc, S, name + ".norm", 1e-6, False)
+        h = A.get(B, S, Cc)
+        self._gemm(g.view(B * S, Cc), W[name + ".proj_in.weight"], h.view(B * S, Cc), bias=W[name + ".proj_in.bias"])
+        A.put(g)
+        vt = self._vt_buf(Cc, S)
+        for i in range(n):
+            tb = f"{name}.transformer_blocks.{i}"
+            a1, a2 = tb + ".attn1", tb + ".attn2"
+            # --- self attention
+            y = self._ln(h, tb + ".norm1", B * S, Cc)
+            qk = A.get(B, S, 2 * Cc)
+            self._proj(y, a1 + ".qkv", qk, S, Cc, out_t=vt, n_trans_begin=2 * Cc)
+            A.put(y)
+            ao = A.get(B, S, Cc)
+            self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
+            A.put(qk)
+            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h)
+            A.put(ao)
+            # --- cross attention against the cached K / V^T
+            y = self._ln(h, tb + ".norm2", B * S, Cc)
+            q = A.get(B, S, Cc)
+            self._proj(y, a2 + ".q", q, S, Cc)
+            A.put(y)
+            ao = A.get(B, S, Cc)
+            self._attn(q, self.kv.k[a2], self.kv.vt[a2], ao, H, S, self.kv.Lk)
+            A.put(q)
+            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h)
+            A.put(ao)
+            # --- feed forward (GEGLU fused in the first GEMM's epilogue)
+            y = self._ln(h, tb + ".norm3", B * S, Cc)
+            f = A.get(B * S, 4 * Cc)
+            self._gemm(y.view(B * S, Cc), W[tb + ".ff1"], f, bias=W[tb + ".ff1.bias"], geglu=True)
+            A.put(y)
+            self._gemm(f, W[tb + ".ff.net.2.weight"], h.view(B * S, Cc), bias=W[tb + ".ff.net.2.bias"], residual=h.view(B * S, Cc))
+            A.put(f)
+        out = A.get(B, S, Cc)
+        self._gemm(h.view(B * S, Cc), W[name + ".proj_out.weight"], out.view(B * S, Cc), bias=W[name + ".proj_out.bias"],
+                   residual=x.view(B * S, Cc))
+        A.put(h)
+        return out
+
+    def _cat(self, x1, C1, x2, C2, HW):
+        out = self.arena.get(self.B, HW, C1 + C2)
+        self._emit(self.lib.tmix_concat_channels, x1.data_ptr(), C1, x2.data_ptr(), C2, out.data_ptr(), self.B * HW)
+        return out
+
+    # ------------------------------------------------------------------ whole network
+    def _build(self):
+        cfg, W, B, A = self.cfg, self.W, self.B, self.arena
+        lib = self.lib
+        ch = cfg.block_out_channels
+        C0, T = ch[0], cfg.time_embed_dim
+        nb = len(ch)
+        # time embedding: sinusoid(t) -> linear_1 -> SiLU -> linear_2 (+ static aug_emb)
+        tsin = torch.empty(B, C0, device=self.dev, dtype=F32)
+        thid = torch.empty(B, T, device=self.dev, dtype=F32)
+        emb = torch.empty(B, T, device=self.dev, dtype=F32)
+        self.keep += [tsin, thid, emb]
+        self._emit(lib.tmix_timestep_embedding, self.t_dev.data_ptr(), tsin.data_ptr(), B, C0)
+        self._emit(lib.tmix_linear_small, tsin.data_ptr(), W["time_embedding.linear_1.weight"].data_ptr(),
+                   W["time_embedding.linear_1.bias"].data_ptr(), None, thid.data_ptr(), B, T, C0, 0, 1)
+        self._emit(lib.tmix_linear_small, thid.data_ptr(), W["time_embedding.linear_2.weight"].data_ptr(),
+                   W["time_embedding.linear_2.bias"].data_ptr(), self.aug.data_ptr(), emb.data_ptr(), B, T, T, 0, 0)
+        Hh, Ww = self.h, self.w
+        x = A.get(B, Hh * Ww, C0)
+        self._emit(lib.tmix_conv_in, self.latent.data_ptr(), W["conv_in.weight"].data_ptr(), W["conv_in.bias"].data_ptr(),
+                   x.data_ptr(), B, cfg.in_channels, Hh, Ww, C0)
+        skips = [(x, C0)]
+        ci = C0
+        for bi, co in enumerate(ch):
+            for j in range(cfg.layers_per_block):
+                xin = x
+                x = self._resnet(xin, ci, co, Hh, Ww, f"down_blocks.{bi}.resnets.{j}", emb)
+                if cfg.transformer_layers[bi]:
+                    x2 = self._t2d(x, co, Hh, Ww, f"down_blocks.{bi}.attentions.{j}", cfg.transformer_layers[bi])
+                    A.put(x)
+                    x = x2
+                ci = co
+                skips.append((x, co))
+            if bi < nb - 1:
+                x = self._conv(x, f"down_blocks.{bi}.downsamplers.0.conv", Hh, Ww, co, co, mode=L.CONV_S2)
+                Hh, Ww = Hh // 2, Ww // 2
+                skips.append((x, co))
+        cm = ch[-1]
+        x2 = self._resnet(x, cm, cm, Hh, Ww, "mid_block.resnets.0", emb)
+        x3 = self._t2d(x2, cm, Hh, Ww, "mid_block.attentions.0", cfg.transformer_layers[-1])
+        A.put(x2)
+        x = self._resnet(x3, cm, cm, Hh, Ww, "mid_block.resnets.1", emb)
+        A.put(x3)
+        for ui, co in enumerate(reversed(ch)):
+            bi = nb - 1 - ui
+            for j in range(cfg.layers_per_block + 1):
+                sk, cs = skips.pop()
+                xc = self._cat(x, ci, sk, cs, Hh * Ww)
+                A.put(x, sk)
+                x = self._resnet(xc, ci + cs, co, Hh, Ww, f"up_blocks.{ui}.resnets.{j}", emb)
+                A.put(xc)
+                if cfg.transformer_layers[bi]:
+                    x2 = self._t2d(x, co, Hh, Ww, f"up_blocks.{ui}.attentions.{j}", cfg.transformer_layers[bi])
+                    A.put(x)
+                    x = x2
+                ci = co
+            if ui < nb - 1:
+                x2 = self._conv(x, f"up_blocks.{ui}.upsamplers.0.conv", Hh, Ww, co, co, mode=L.CONV_UP2)
+                A.put(x)
+                x = x2
+                Hh, Ww = Hh * 2, Ww * 2
+        y = self._gn(x, C0, Hh * Ww, "conv_norm_out", 1e-5, True)
+        A.put(x)
+        self._emit(lib.tmix_conv_out, y.data_ptr(), W["conv_out.weight"].data_ptr(), W["conv_out.bias"].data_ptr(),
+                   self.eps.data_ptr(), B, C0, Hh, Ww, cfg.out_channels)
+        self.flops += 2 * B * Hh * Ww * 9 * (cfg.in_channels * C0 + C0 * cfg.out_channels)
+        self.ops = [(fn, tuple(a)) for fn, a in self.ops]
+
+    # ------------------------------------------------------------------ execution
+    def run(self, stream=None):
+        """enqueue the whole forward on `stream` (default: torch's current stream). No sync, no alloc."""
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        for fn, args in self.ops:
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, fn.__name__)
+
+    def __call__(self, latent, t):
+        """eps = unet(latent[B,4,h,w], t) with this plan's prompt rows.  Returns the plan's eps buffer."""
+        self.latent.copy_(latent)
+        self.t_dev.fill_(float(t))
+        self.run()
+        return self.eps

@@ -13,3 +13,146 @@ def interleave_geglu(w: torch.Tensor, b: torch.Tensor | None):
     assert n % 16 == 0
     idx = torch.arange(n2, device=w.device).reshape(2, n // 16, 16).permute(1, 0, 2).reshape(-1)
     return w[idx].contiguous(), (None if b is None else b[idx].contiguous())
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter inventory (diffusers key scheme) and synthetic weights / concept deltas
+# ----------------------------------------------------------------------------------------------
+def param_shapes(cfg) -> dict:
+    """name -> shape of every UNet2DConditionModel parameter for `cfg` (SDXL-base layout)."""
+    P = {}
+    C0, T = cfg.block_out_channels[0], cfg.time_embed_dim
+
+    def lin(name, i, o, bias=True):
+        P[name + ".weight"] = (o, i)
+        if bias:
+            P[name + ".bias"] = (o,)
+
+    def conv(name, i, o, k=3):
+        P[name + ".weight"] = (o, i, k, k)
+        P[name + ".bias"] = (o,)
+
+    def norm(name, c):
+        P[name + ".weight"] = (c,)
+        P[name + ".bias"] = (c,)
+
+    def resnet(name, ci, co):
+        norm(name + ".norm1", ci)
+        conv(name + ".conv1", ci, co)
+        lin(name + ".time_emb_proj", T, co)
+        norm(name + ".norm2", co)
+        conv(name + ".conv2", co, co)
+        if ci != co:
+            conv(name + ".conv_shortcut", ci, co, 1)
+
+    def t2d(name, c, n):
+        norm(name + ".norm", c)
+        lin(name + ".proj_in", c, c)
+        for i in range(n):
+            b = f"{name}.transformer_blocks.{i}"
+            norm(b + ".norm1", c)
+            for a, kd in (("attn1", c), ("attn2", cfg.cross_dim)):
+                lin(f"{b}.{a}.to_q", c, c, False)
+                lin(f"{b}.{a}.to_k", kd, c, False)
+                lin(f"{b}.{a}.to_v", kd, c, False)
+                lin(f"{b}.{a}.to_out.0", c, c)
+            norm(b + ".norm2", c)
+            norm(b + ".norm3", c)
+            lin(b + ".ff.net.0.proj", c, 8 * c)
+            lin(b + ".ff.net.2", 4 * c, c)
+        lin(name + ".proj_out", c, c)
+
+    conv("conv_in", cfg.in_channels, C0)
+    lin("time_embedding.linear_1", C0, T)
+    lin("time_embedding.linear_2", T, T)
+    lin("add_embedding.linear_1", cfg.add_in_dim, T)
+    lin("add_embedding.linear_2", T, T)
+    ch = cfg.block_out_channels
+    nb = len(ch)
+    skip, ci = [C0], C0
+    for bi, co in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{bi}.resnets.{j}", ci, co)
+            if cfg.transformer_layers[bi]:
+                t2d(f"down_blocks.{bi}.attentions.{j}", co, cfg.transformer_layers[bi])
+            ci = co
+            skip.append(co)
+        if bi < nb - 1:
+            conv(f"down_blocks.{bi}.downsamplers.0.conv", co, co)
+            skip.append(co)
+    cm = ch[-1]
+    resnet("mid_block.resnets.0", cm, cm)
+    t2d("mid_block.attentions.0", cm, cfg.transformer_layers[-1])
+    resnet("mid_block.resnets.1", cm, cm)
+    for ui, co in enumerate(reversed(ch)):
+        bi = nb - 1 - ui
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"up_blocks.{ui}.resnets.{j}", ci + skip.pop(), co)
+            if cfg.transformer_layers[bi]:
+                t2d(f"up_blocks.{ui}.attentions.{j}", co, cfg.transformer_layers[bi])
+            ci = co
+        if ui < nb - 1:
+            conv(f"up_blocks.{ui}.upsamplers.0.conv", co, co)
+    norm("conv_norm_out", C0)
+    conv("conv_out", C0, cfg.out_channels)
+    return P
+
+
+def synthetic_state_dict(cfg, seed=1234, device="cpu", nontrivial=False, dtype=torch.float32):
+    """Random-init weights of the SDXL architecture (there are no checkpoints offline):
+    Linear/conv ~ N(0, 1/fan_in), biases 0, norms (1, 0); residual-branch outputs (to_out, ff.net.2,
+    conv2, proj_out) x0.1 so activations stay O(1) through 70 blocks.  Values are rounded to bf16
+    (what the kernels consume) and returned in `dtype`.  nontrivial=True also randomises biases and
+    norm affine parameters so tests exercise them."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in param_shapes(cfg).items():
+        is_norm = ".norm" in name or name.startswith("conv_norm_out")
+        if name.endswith(".bias"):
+            v = torch.randn(shape, generator=gen, device=device) * 0.1 if nontrivial else torch.zeros(shape, device=device)
+        elif is_norm:
+            v = torch.ones(shape, device=device)
+            if nontrivial:
+                v = v + 0.1 * torch.randn(shape, generator=gen, device=device)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            v = torch.randn(shape, generator=gen, device=device) * fan_in ** -0.5
+            if any(k in name for k in (".to_out.0.", ".ff.net.2.", ".conv2.", ".proj_out.")):
+                v = v * 0.1
+        sd[name] = v.to(torch.bfloat16).to(dtype)
+    return sd
+
+
+def attention_block_prefixes(cfg):
+    return sorted({k.rsplit(".attn1", 1)[0] for k in param_shapes(cfg) if ".attn1.to_q" in k})
+
+
+def synthetic_concepts(cfg, kind, K, device="cpu", dtype=torch.float32):
+    """K concept checkpoints in the reference's own 'unet' key scheme:
+    custom: '<tb>.attn2.to_k.weight' / 'to_v.weight' ([C,cross], seed 2000+i)   (diffusers_training_xl_new.py:45-66)
+    lora  : '<tb>.attn{1,2}.processor.to_{q,k,v,out}_lora.{down,up}.weight', rank 4, down ~ N(0,1/4),
+            up ~ N(0,0.02) (seed 3000+i)                                         (model_lora.py:28-48,104-115)"""
+    shapes = param_shapes(cfg)
+    out = []
+    for i in range(K):
+        sd = {}
+        if kind == "custom":
+            gen = torch.Generator(device=device).manual_seed(2000 + i)
+            for tb in attention_block_prefixes(cfg):
+                for nm in ("to_k", "to_v"):
+                    shp = shapes[f"{tb}.attn2.{nm}.weight"]
+                    sd[f"{tb}.attn2.{nm}.weight"] = (torch.randn(shp, generator=gen, device=device) * shp[1] ** -0.5).to(torch.bfloat16).to(dtype)
+        elif kind == "lora":
+            gen = torch.Generator(device=device).manual_seed(3000 + i)
+            for tb in attention_block_prefixes(cfg):
+                for a in ("attn1", "attn2"):
+                    for nm, wn in (("q", "to_q"), ("k", "to_k"), ("v", "to_v"), ("out", "to_out.0")):
+                        o, ii = shapes[f"{tb}.{a}.{wn}.weight"]
+                        sd[f"{tb}.{a}.processor.to_{nm}_lora.down.weight"] = (torch.randn(4, ii, generator=gen, device=device) * 0.25).to(dtype)
+                        sd[f"{tb}.{a}.processor.to_{nm}_lora.up.weight"] = (torch.randn(o, 4, generator=gen, device=device) * 0.02).to(dtype)
+        else:
+            raise ValueError(kind)
+        out.append(sd)
+    return out
