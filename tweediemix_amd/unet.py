@@ -199,6 +199,7 @@ class _Arena:
 
     def __init__(self, device):
         self.device, self.free, self.total = device, {}, 0
+        self.bufs = []          # owns every buffer for the plan's lifetime (views handed out are not owners)
 
     def get(self, *shape, dtype=BF16):
         n = 1
@@ -210,6 +211,7 @@ class _Arena:
             buf = lst.pop()
         else:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.bufs.append(buf)
             self.total += nbytes
         tns = buf.view(dtype)[:n].view(*shape)
         tns._arena_buf = buf
