@@ -164,12 +164,11 @@ def main():
     dt = time.perf_counter() - t0
     assert torch.isfinite(x).all()
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        # result gather (the only collective on this path): final latents of every rank
-        gathered = torch.empty(world, *x.shape[1:], device=device)
-        dist.all_gather_into_tensor(gathered, x.contiguous())
+        from tweediemix_amd import dist as D
+        dt = D.max_over_ranks(dt, device)
+        # result gather (the only collective on this path): final latents of every rank's seeds
+        gathered = D.gather_latents(x.contiguous(), world, rank, world)
+        assert gathered.shape[0] == world and torch.isfinite(gathered).all()
 
     if rank == 0:
         roof = gemm_roofline(plan)
