@@ -89,6 +89,20 @@ def gemm_roofline(plan):
             e1.record()
             ev[key].append((e0, e1))
     torch.cuda.synchronize()
+    if os.environ.get("TMIX_BENCH_SHAPES"):
+        import collections
+        agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for (d, fl), (a, b) in zip(plan.launches["gemm"], ev["gemm"]):
+            k = ("gemm", d.batch, d.M, d.N, d.K, "geglu" if d.epilogue else "", "T" if d.n_trans_begin >= 0 else "", d.tile_cfg)
+            agg[k][0] += 1; agg[k][1] += a.elapsed_time(b); agg[k][2] += fl
+        for (d, fl), (a, b) in zip(plan.launches["conv"], ev["conv"]):
+            k = ("conv", d.B, d.H, d.W, d.Cin, d.Cout, d.mode, d.tile_cfg)
+            agg[k][0] += 1; agg[k][1] += a.elapsed_time(b); agg[k][2] += fl
+        for (args, fl), (a, b) in zip(plan.launches["attn"], ev["attn"]):
+            k = ("attn", args[12], args[13], args[14], args[15])
+            agg[k][0] += 1; agg[k][1] += a.elapsed_time(b); agg[k][2] += fl
+        for k, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {str(k):60s} n={n:4d} total={ms:7.3f}ms avg={1e3 * ms / n:7.1f}us {fl / ms / 1e9:6.0f}TF", file=sys.stderr)
     out = {}
     for key in ev:
         ms = [a.elapsed_time(b) for a, b in ev[key]]

@@ -67,6 +67,9 @@ int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, cons
  * Requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned pointers.
  */
 enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1 };
+/* workgroup tilings of the MFMA mainloop (BM x BN, waves, LDS ring depth); AUTO = built-in heuristic */
+enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, TMIX_TILE_128x128_S4 = 3,
+       TMIX_TILE_256x256_S2 = 4, TMIX_TILE_COUNT = 4 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */
@@ -79,6 +82,7 @@ typedef struct {
     int32_t n_trans_begin;                       /*   Ct[b][n - n_trans_begin][m]; <0 = none       */
     int32_t M, N, K, batch;
     int32_t epilogue;
+    int32_t tile_cfg;                            /* TMIX_TILE_AUTO or a specific tiling (autotuned by the host) */
 } tmix_gemm_desc;
 int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
 
@@ -96,6 +100,7 @@ typedef struct {
     const float* batch_bias;     /* fp32 [B][Cout] (time embedding) or NULL   */
     const void* residual;        /* bf16 like Y or NULL                       */
     int32_t B, H, W, Cin, Cout, mode;
+    int32_t tile_cfg;            /* TMIX_TILE_*                                */
 } tmix_conv_desc;
 int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
 

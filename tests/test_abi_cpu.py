@@ -34,9 +34,9 @@ def test_descriptor_layouts():
     assert lib.GemmDesc.bias.offset == 72 and lib.GemmDesc.residual.offset == 88
     assert lib.GemmDesc.rowgroup_bias.offset == 112 and lib.GemmDesc.rows_per_group.offset == 120
     assert lib.GemmDesc.Ct.offset == 128 and lib.GemmDesc.n_trans_begin.offset == 152
-    assert lib.GemmDesc.M.offset == 156 and lib.GemmDesc.epilogue.offset == 172
-    assert ctypes.sizeof(lib.GemmDesc) == 176
-    assert lib.ConvDesc.B.offset == 48 and ctypes.sizeof(lib.ConvDesc) == 72
+    assert lib.GemmDesc.M.offset == 156 and lib.GemmDesc.epilogue.offset == 172 and lib.GemmDesc.tile_cfg.offset == 176
+    assert ctypes.sizeof(lib.GemmDesc) == 184
+    assert lib.ConvDesc.B.offset == 48 and lib.ConvDesc.tile_cfg.offset == 72 and ctypes.sizeof(lib.ConvDesc) == 80
 
 
 def test_geometry_helper_without_gpu():

@@ -86,45 +86,49 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
-                                   (1024, 1280, 640), (130, 132, 192)])
-def test_gemm_plain(ops, M, N, K):
+                                   (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
+def test_gemm_plain(ops, M, N, K, cfg):
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
-    out = ops.gemm(a, w)
+    out = ops.gemm(a, w, tile_cfg=cfg)
     close(out, a.float() @ w.float().T)
 
 
-def test_gemm_epilogues(ops):
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
     bias = rnd(N, seed=5, dtype=torch.float32)
     res = rnd(M, N, seed=6)
     rgb = rnd(3, N, seed=7, dtype=torch.float32)
-    out = ops.gemm(a, w, bias=bias, residual=res, rowgroup_bias=rgb, rows_per_group=128)
+    out = ops.gemm(a, w, bias=bias, residual=res, rowgroup_bias=rgb, rows_per_group=128, tile_cfg=cfg)
     ref = a.float() @ w.float().T + bias + res.float() + rgb.repeat_interleave(128, 0)
     close(out, ref)
 
 
-def test_gemm_geglu(ops):
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
     w = rnd(8 * C, C, seed=9, scale=C ** -0.5)           # torch layout: rows [0,4C) value, [4C,8C) gate
     b = rnd(8 * C, seed=10, dtype=torch.float32)
     from tweediemix_amd.weights import interleave_geglu
     wi, bi = interleave_geglu(w, b)
-    out = ops.gemm(a, wi, bias=bi, geglu=True)
+    out = ops.gemm(a, wi, bias=bi, geglu=True, tile_cfg=cfg)
     y = a.float() @ w.float().T + b
     ref = y[:, :4 * C] * F.gelu(y[:, 4 * C:])
     close(out, ref)
 
 
-def test_gemm_batched_weights_and_transposed_out(ops):
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     Bz, M, C = 3, 100, 128
     a = rnd(Bz, M, C, seed=11)
     w = rnd(Bz, 3 * C, C, seed=12, scale=C ** -0.5)      # one weight set per batch row (concept routing)
     ldvt = 104
     vt = torch.zeros(Bz, C, ldvt, device="cuda", dtype=BF)
-    qk = ops.gemm(a, w, out_t=vt, n_trans_begin=2 * C)
+    qk = ops.gemm(a, w, out_t=vt, n_trans_begin=2 * C, tile_cfg=cfg)
     ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float())
     close(qk, ref[:, :, :2 * C])
     close(vt[:, :, :M], ref[:, :, 2 * C:].transpose(1, 2))
@@ -144,16 +148,17 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 # --------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 10, 6, 128, 68), (3, 8, 8, 320, 320)])
-def test_conv3x3(ops, mode, B, H, W, Cin, Cout):
+def test_conv3x3(ops, mode, B, H, W, Cin, Cout, cfg):
     x = rnd(B, H, W, Cin, seed=20)
     w = rnd(Cout, 3, 3, Cin, seed=21, scale=(9 * Cin) ** -0.5)
     bias = rnd(Cout, seed=22, dtype=torch.float32)
     temb = rnd(B, Cout, seed=23, dtype=torch.float32)
     Ho, Wo = ops.conv_out_hw(H, W, mode)
     res = rnd(B, Ho, Wo, Cout, seed=24)
-    out = ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=res, mode=mode)
+    out = ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=res, mode=mode, tile_cfg=cfg)
     xn = x.float().permute(0, 3, 1, 2)
     wn = w.float().permute(0, 3, 1, 2)
     if mode == 2:

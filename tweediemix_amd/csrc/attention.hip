@@ -15,6 +15,7 @@
 //
 // MFMA roofline: 4*Sq*Skv*64 flops per (batch, head).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -25,7 +26,9 @@ constexpr int QB = 128;          // query rows per workgroup (32 per wave)
 constexpr int KB = 64;           // keys per tile
 constexpr int TILE = KB * 64 * 2;    // 8 KiB (K tile or V^T tile)
 constexpr int STAGE = 2 * TILE;
-constexpr int SMEM = 2 * STAGE;      // 32 KiB
+constexpr int NS = 3;                // LDS ring depth: NS-1 tiles requested ahead, NS-2 in flight across a barrier
+constexpr int SMEM = NS * STAGE;     // 48 KiB -> 3 workgroups per CU
+constexpr int LOADS = 4;             // LDS-DMA instructions per wave per tile
 
 struct AttnParams {
     const bf16_t* Q; int64_t ldq, strideQ;
@@ -41,12 +44,33 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// cross-lane reductions over the 4 lane groups (lane ^ 16, lane ^ 32) with gfx950's VALU row/half swaps
+// instead of ds_bpermute: no LDS round trip (8 dependent ~100-cycle LDS latencies per tile otherwise).
+__device__ __forceinline__ float xor16_max(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     bf16x2_t v = {(__bf16)a, (__bf16)b};
     return *(uint32_t*)&v;
 }
 
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, 3) attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,17 +108,22 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
         vrow[r] = rho;
     }
     const int nt = (p.Skv + KB - 1) / KB;
+    // per-lane source offsets stay 32-bit (elements); the 64-bit bases are wave-uniform
+    const int ldk = (int)p.ldk, ldvt = (int)p.ldvt;
+    int voff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) voff[r] = vrow[r] * ldvt;
     auto stage = [&](int buf, int t) {
         char* sK = smem + buf * STAGE;
         char* sV = sK + TILE;
         const int kv0 = t * KB;
+        int c = kv0 + schunk; if (c > ldvt - 8) c = ldvt - 8;       // fully masked chunk: any finite data
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int off = (r * 4 + w) * 1024;
             int key = kv0 + krow[r]; if (key > p.Skv - 1) key = p.Skv - 1;
-            glds16(Kb + (int64_t)key * p.ldk + schunk, sK + off);
-            int64_t c = kv0 + schunk; if (c > p.ldvt - 8) c = p.ldvt - 8;   // fully masked chunk: any finite data
-            glds16(Vb + (int64_t)vrow[r] * p.ldvt + c, sV + off);
+            glds16(Kb + (unsigned)(key * ldk + schunk), sK + off);
+            glds16(Vb + (unsigned)(voff[r] + c), sV + off);
         }
     };
 
@@ -103,15 +132,12 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     for (int i = 0; i < 4; ++i) { o[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
 
-    stage(0, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    // one KV tile: S^T = K Q^T, online softmax in registers, O^T += V^T P^T.  MASK = tile holds keys >= Skv.
+    const float c = p.scale_log2e;                   // softmax(x*scale) = exp2(x*c - max*c) / sum
+    auto tile = [&](int cur, int kv0, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const char* sK = smem + cur * STAGE;
         const char* sV = sK + TILE;
-
-        // ---- S^T fragments: s[f][qi] holds keys kappa(f, 4fg+r), query qi*16+fr
         f32x4 s[4][2];
 #pragma unroll
         for (int f = 0; f < 4; ++f) { s[f][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; s[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -125,57 +151,54 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
                 s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ds], s[f][1], 0, 0, 0);
             }
         }
-
-        // ---- online softmax (per query column; keys are spread over r, f and the 4 lane groups)
-        const int kv0 = t * KB;
-        const bool partial = (kv0 + KB > p.Skv);
-        uint32_t pb[2][2][4];          // [qi][k-step p] packed bf16x8 = B operand of O^T = V^T P^T
+        uint32_t pb[2][2][4];          // [qi][k-step] packed bf16x8 = B operand of O^T = V^T P^T
+        float alpha[2];
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            float mx = -INFINITY;
+            // x = s*c first (packed multiplies): the products are canonical, so the max tree below needs no
+            // per-operand canonicalising v_max (which fmaxf on raw MFMA outputs would get).
+            f32x4 x[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f) x[f] = s[f][qi] * c;
+            if constexpr (MASK) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[f][qi][r] * p.scale_log2e;
-                    if (partial) {
-                        const int key = kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r;
-                        if (key >= p.Skv) v = -INFINITY;
-                    }
-                    s[f][qi][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qi], mx);          // finite: tile 0 always has a valid key
-            const float alpha = exp2f(mrun[qi] - mnew);
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) x[f][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3]));
+#pragma unroll
+            for (int f = 1; f < 4; ++f) mx = fmaxf(fmaxf(mx, fmaxf(x[f][0], x[f][1])), fmaxf(x[f][2], x[f][3]));
+            mx = xor32_max(xor16_max(mx));
+            const float mnew = fmaxf(mrun[qi], mx);          // finite: tile 0 always holds a valid key
+            alpha[qi] = __builtin_amdgcn_exp2f(mrun[qi] - mnew);
             mrun[qi] = mnew;
-            float sum = 0.f;
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f) {
+                x[f] = x[f] - mnew;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[f][qi][r] - mnew);
-                    s[f][qi][r] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            lrun[qi] = lrun[qi] * alpha + sum;
-#pragma unroll
-            for (int df = 0; df < 4; ++df)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[df][qi][r] *= alpha;
+                for (int r = 0; r < 4; ++r) x[f][r] = __builtin_amdgcn_exp2f(x[f][r]);
+                acc4 += x[f];
+            }
+            float sum = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            sum = xor32_sum(xor16_sum(sum));
+            lrun[qi] = lrun[qi] * alpha[qi] + sum;
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
-                pb[qi][ps][0] = pk_bf16(s[2 * ps][qi][0], s[2 * ps][qi][1]);
-                pb[qi][ps][1] = pk_bf16(s[2 * ps][qi][2], s[2 * ps][qi][3]);
-                pb[qi][ps][2] = pk_bf16(s[2 * ps + 1][qi][0], s[2 * ps + 1][qi][1]);
-                pb[qi][ps][3] = pk_bf16(s[2 * ps + 1][qi][2], s[2 * ps + 1][qi][3]);
+                pb[qi][ps][0] = pk_bf16(x[2 * ps][0], x[2 * ps][1]);
+                pb[qi][ps][1] = pk_bf16(x[2 * ps][2], x[2 * ps][3]);
+                pb[qi][ps][2] = pk_bf16(x[2 * ps + 1][0], x[2 * ps + 1][1]);
+                pb[qi][ps][3] = pk_bf16(x[2 * ps + 1][2], x[2 * ps + 1][3]);
             }
         }
-
-        // ---- O^T += V^T P^T
+        // rescale the running output only when some row's maximum actually moved (wave-uniform branch)
+        if (__any((alpha[0] != 1.0f) | (alpha[1] != 1.0f))) {
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+            { o[df][0] *= alpha[0]; o[df][1] *= alpha[1]; }
+        }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int sw = ((ps * 4 + fg) ^ (fr & 7)) << 4;
@@ -189,8 +212,28 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
                 o[df][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p1, o[df][1], 0, 0, 0);
             }
         }
-        __syncthreads();
-        cur ^= 1;
+    };
+
+    // K/V tiles are small (16 KiB) and a tile's compute is shorter than the L2->LDS latency, so the loop keeps
+    // NS-2 tiles in flight across each barrier (counted vmcnt + raw s_barrier, as in the GEMM mainloop).
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) stage(s, s);
+    if (nt >= NS - 1) wait_vmcnt<(NS - 2) * LOADS>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0, nxt = NS - 1;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + NS - 1 < nt;
+        if (more) stage(nxt, t + NS - 1);
+        const int kv0 = t * KB;
+        if (kv0 + KB > p.Skv) tile(cur, kv0, std::true_type{});
+        else                  tile(cur, kv0, std::false_type{});
+        if (more) wait_vmcnt<(NS - 2) * LOADS>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 
     // ---- epilogue: O[q][h*64 + df*16 + fg*4 + r] = o / l
@@ -217,6 +260,7 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
                              int B, int H, int Sq, int Skv, float scale, void* stream) {
     if (!Q || !K || !Vt || !O) TMIX_FAIL(TMIX_EINVAL, "attn: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) TMIX_FAIL(TMIX_ESHAPE, "attn: empty problem B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
+    if ((int64_t)Skv * ldk >= (1ll << 31) || 64 * ldvt >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "attn: per-head K/V extent exceeds 32-bit offsets");
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (strideQ % 8) || (strideK % 8) || (strideVt % 8) || (strideO % 4))
         TMIX_FAIL(TMIX_EALIGN, "attn: leading dims / strides must keep 16-byte (Q,K,Vt) / 8-byte (O) alignment");
     if (ldvt < ((Skv + 7) / 8) * 8) TMIX_FAIL(TMIX_ESHAPE, "attn: ldvt=%lld < Skv rounded up to 8", (long long)ldvt);

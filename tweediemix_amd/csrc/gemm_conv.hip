@@ -1,26 +1,27 @@
 // gemm_conv.hip -- bf16 MFMA GEMM (C = A * W^T) and 3x3 NHWC implicit-GEMM convolution for gfx950.
 //
-// One templated mainloop serves both: a 128x128 output tile per 256-thread workgroup (4 waves, 2x2,
-// 64x64 per wave = 4x4 fragments of v_mfma_f32_16x16x32_bf16), BK = 64, operands staged HBM->LDS with
-// global_load_lds_dwordx4 (no VGPR round trip) into a double-buffered, XOR-swizzled LDS image:
-// the LDS destination of an LDS-DMA is lane-linear, so the swizzle is applied to each lane's SOURCE
-// address (16-byte chunk c of row r is stored at chunk position c ^ (r & 7)) and undone on the
-// ds_read_b128 side -- conflict-free for the 16-lane read groups of ds_read_b128.
-// The convolution differs only in how a lane finds its source address (im2col on the fly: K-tile kt
-// is tap kt / (Cin/64), channels (kt % (Cin/64))*64..+63 of the shifted pixel; padding taps read a
-// zero page).  Fused epilogues: bias, per-row-group bias (time embedding), residual add, GEGLU,
-// and a transposed store (V^T for the attention kernel).
+// One templated mainloop <BM, BN, WM x WN waves, NS stages> serves both:
+//   * operands are staged HBM->LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into an
+//     NS-deep ring of [rows][64] bf16 tiles; the loop keeps NS-2 whole K-tiles in flight across the
+//     per-tile barrier with COUNTED s_waitcnt vmcnt(N) + raw s_barrier (never a draining __syncthreads),
+//     because these GEMMs are latency-bound, not MFMA-bound, with a one-tile prefetch distance;
+//   * the LDS image is XOR-swizzled: 16-byte chunk c of row r lives at chunk position c ^ ((r>>1)&7).
+//     LDS-DMA destinations are lane-linear, so the permutation is applied to each lane's SOURCE address
+//     and undone on the ds_read_b128 side; it is conflict-free for the 16-lane service groups of
+//     ds_read_b128 with 32-row MFMA fragments;
+//   * v_mfma_f32_32x32x16_bf16, wave tile (BM/WM) x (BN/WN), fp32 accumulation;
+//   * the convolution differs only in how a lane finds its source address (im2col on the fly: K-tile kt
+//     is tap kt / (Cin/64), channels (kt % (Cin/64))*64..+63 of the shifted pixel; padding taps read a
+//     zero page); stride-2 and nearest-x2 upsampling are folded into the gather;
+//   * fused epilogues: bias, per-row-group bias (time embedding), residual add, GEGLU, transposed store
+//     (V^T for the attention kernel), per-batch weight sets (concept routing).
 //
 // MFMA roofline: 2*M*N*K flops per launch against the 2.5 PFLOP/s dense bf16 peak.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // double buffer = 64 KiB -> 2 workgroups per CU
-
+constexpr int BK = 64;
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // 256 B of zeros (conv padding taps)
@@ -33,7 +34,7 @@ struct Params {
     const bf16_t* R; int64_t ldr, strideR;
     const float* rgb; int rows_per_group;
     bf16_t* Ct; int64_t ldct, strideCt; int n_trans_begin;
-    int M, N, K, tiles_m, tiles_n, epilogue;
+    int M, N, K, tiles_m, tiles_n, group_m, epilogue;
     // convolution geometry (CONV only)
     int H, Wd, Cin, Ho, Wo, mode;
 };
@@ -43,66 +44,66 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <bool SWAP>
-__device__ __forceinline__ void mma_tile(const char* sA, const char* sW, int wr, int wc, int fr, int fg,
-                                         f32x4 (&acc)[4][4]) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int sw = ((kk * 4 + fg) ^ (fr & 7)) << 4;
-        frag_ab a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] = *(const frag_ab*)(sA + (wr * 64 + i * 16 + fr) * 128 + sw);
-            b[i] = *(const frag_ab*)(sW + (wc * 64 + i * 16 + fr) * 128 + sw);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                if constexpr (SWAP)   // D[n][m]: lane holds 4 consecutive n for one m (row-major C stores)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
-                else                  // D[m][n]: lane holds 4 consecutive m for one n (transposed stores)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            }
-    }
-}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int CONV>
-__global__ void __launch_bounds__(256, 2) gemm_conv_kernel(const Params p) {
+template <int BM, int BN, int WM, int WN, int NS, int CONV>
+__global__ void __launch_bounds__(WM * WN * 64) gemm_conv_kernel(const Params p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
+    constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
+    constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
+    constexpr int RA = BM / 8 / NW, RB = BN / 8 / NW;  // LDS-DMA instructions per wave per stage
+    constexpr int L = RA + RB;
+    static_assert(RA >= 1 && RB >= 1 && FM >= 1 && FN >= 1, "tile/wave geometry");
+    static_assert((NS - 2) * L <= 63, "vmcnt immediate");
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    const int fr = lane & 15, fg = lane >> 4;
+    const int wr = w / WN, wc = w - wr * WN;
 
+    // Tile order: each XCD (private 4 MiB L2) owns a contiguous range of logical ids, and ids sweep GM tile-rows
+    // per tile-column, so the ~64 tiles resident on an XCD at any time form a compact GM x (64/GM) patch that
+    // shares GM A-panels and 64/GM W-panels instead of streaming one W-panel per tile through the L2.
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int per_group = p.group_m * p.tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * p.group_m;
+    const int gsize = min(p.tiles_m - first_m, p.group_m);
+    const int rem = bid - grp * per_group;
+    const int tile_n = rem / gsize, tile_m = first_m + (rem - tile_n * gsize);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int bz = blockIdx.y;
 
     const bf16_t* Ab = p.A + (int64_t)bz * p.strideA;
     const bf16_t* Wb = p.W + (int64_t)bz * p.strideW;
 
-    // ---- per-lane staging sources: 4 rounds x (8 rows x 8 chunks) per wave-instruction
-    const int lrow = lane >> 3;                       // row within the 8-row group
-    const int schunk = ((lane & 7) ^ lrow) * 8;       // swizzled source chunk (elements)
-    const bf16_t* wsrc[4];
-    const bf16_t* asrc[4];
-    int pb[4], py[4], px[4];                          // conv: decoded output pixel per round
+    // ---- per-lane staging sources. Wave-instruction idx = r*NW + w covers LDS rows idx*8 .. idx*8+7.
+    const int lrow = lane >> 3;
+    const bf16_t* wsrc[RB];
+    const bf16_t* asrc[RA];
+    int pb[RA], py[RA], px[RA], asw[RA];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = (r * 4 + w) * 8 + lrow;
-        int n = n0 + row; if (n > p.N - 1) n = p.N - 1;
-        wsrc[r] = Wb + (int64_t)n * p.ldw + schunk;
-        int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
+    for (int r = 0; r < RB; ++r) {
+        const int idx = r * NW + w;
+        const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
+        int n = n0 + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
+        wsrc[r] = Wb + (int64_t)n * p.ldw + sw;
+    }
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int idx = r * NW + w;
+        const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;
+        int m = m0 + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+        asw[r] = sw;
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo;
             pb[r] = m / hw; const int rem = m - pb[r] * hw;
             py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
             asrc[r] = nullptr;
         } else {
-            asrc[r] = Ab + (int64_t)m * p.lda + schunk;
+            asrc[r] = Ab + (int64_t)m * p.lda + sw;
         }
     }
 
@@ -111,13 +112,12 @@ __global__ void __launch_bounds__(256, 2) gemm_conv_kernel(const Params p) {
     const int cpt = CONV ? p.Cin / BK : 1;
 
     auto stage = [&](int buf, int kt) {
-        char* sA = smem + buf * STAGE_BYTES;
-        char* sW = sA + TILE_BYTES;
+        char* sA = smem + buf * STAGE;
+        char* sW = sA + A_TILE;
         int ky = 0, kx = 0;
         if constexpr (CONV) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int off = (r * 4 + w) * 1024;
+        for (int r = 0; r < RA; ++r) {
             const bf16_t* ga;
             if constexpr (CONV) {
                 int iy, ix; bool ok;
@@ -125,128 +125,215 @@ __global__ void __launch_bounds__(256, 2) gemm_conv_kernel(const Params p) {
                 else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
                 else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
                        ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
-                ga = ok ? Ab + ((int64_t)(pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + cc * BK + schunk
-                        : (const bf16_t*)g_zero_page + schunk;
+                ga = ok ? Ab + ((int64_t)(pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + cc * BK + asw[r]
+                        : (const bf16_t*)g_zero_page + asw[r];
             } else {
                 ga = asrc[r] + (int64_t)kt * BK;
             }
-            glds16(ga, sA + off);
-            glds16(wsrc[r] + (int64_t)kt * BK, sW + off);
+            glds16(ga, sA + (r * NW + w) * 1024);
         }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) glds16(wsrc[r] + (int64_t)kt * BK, sW + (r * NW + w) * 1024);
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; } }
     };
 
-    f32x4 acc[4][4];
+    f32x16 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const bool trans = (p.n_trans_begin >= 0) && (n0 >= p.n_trans_begin);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int fsw = (lane >> 1) & 7;                  // f(row) for fragment rows base + (lane & 31)
 
-    stage(0, 0);
-    __syncthreads();
-    int cur = 0;
+    // One MFMA body for both store orientations: acc[i][j] = mfma(b[j], a[i]) yields D[rows of b][rows of a], and
+    // a lane holds 4 consecutive D-rows for one D-column.  Row-major tiles take a = A-tile, b = W-tile fragments
+    // (lane: 4 consecutive n for one m); transposed tiles swap the two LDS sources (square wave tiles only), so
+    // acc[i][j] then belongs to W-fragment i x A-fragment j and a lane holds 4 consecutive m for one n.
+    const int offA = (wr * TM + l31) * 128, offW = A_TILE + (wc * TN + l31) * 128;
+    const int off_a = trans ? offW : offA, off_b = trans ? offA : offW;
+    auto compute = [&](int buf) {
+        const char* pa = smem + buf * STAGE + off_a;
+        const char* pb = smem + buf * STAGE + off_b;
+        // fragments of k-step kk+1 are requested before the MFMAs of k-step kk issue (register double buffer)
+        frag_ab a[2][FM], b[2][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[0][i] = *(const frag_ab*)(pa + i * 32 * 128 + ((lhi ^ fsw) << 4));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + ((lhi ^ fsw) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int sw = (((kk + 1) * 2 + lhi) ^ fsw) << 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[(kk + 1) & 1][i] = *(const frag_ab*)(pa + i * 32 * 128 + sw);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[(kk + 1) & 1][j] = *(const frag_ab*)(pb + j * 32 * 128 + sw);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk & 1][j], a[kk & 1][i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sA = smem + cur * STAGE_BYTES;
-        const char* sW = sA + TILE_BYTES;
-        if (trans) mma_tile<false>(sA, sW, wr, wc, fr, fg, acc);
-        else       mma_tile<true>(sA, sW, wr, wc, fr, fg, acc);
-        __syncthreads();
-        cur ^= 1;
+        const bool more = kt + NS - 1 < nk;
+        if (more) stage(nxt, kt + NS - 1);
+        compute(cur);
+        if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 
     // ---------------------------------------------------------------- epilogue
+    // 32x32 accumulator: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     if (trans) {
-        bf16_t* Ct = p.Ct + (int64_t)bz * p.strideCt;
+        if constexpr (FM == FN && TM == TN) {
+            bf16_t* Ct = p.Ct + (int64_t)bz * p.strideCt;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int m = m0 + wr * 64 + mi * 16 + fg * 4;
-                const int n = n0 + wc * 64 + ni * 16 + fr;
-                if (n >= p.N || m >= p.M) continue;
+            for (int i = 0; i < FM; ++i) {                 // W fragment (output row of Ct)
+                const int n = n0 + wc * TN + i * 32 + l31;
+                if (n >= p.N) continue;
                 const float bv = bias ? bias[n] : 0.f;
-                bf16_t* dst = Ct + (int64_t)(n - p.n_trans_begin) * p.ldct + m;
-                if (m + 3 < p.M && ((p.ldct & 3) == 0)) {
-                    uint2 v;
-                    v.x = pack_bf2(acc[mi][ni][0] + bv, acc[mi][ni][1] + bv);
-                    v.y = pack_bf2(acc[mi][ni][2] + bv, acc[mi][ni][3] + bv);
-                    *(uint2*)dst = v;
-                } else {
+                bf16_t* row = Ct + (int64_t)(n - p.n_trans_begin) * p.ldct;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (m + r < p.M) dst[r] = f2bf(acc[mi][ni][r] + bv);
-                }
+                for (int j = 0; j < FN; ++j)               // A fragment (4 consecutive m per register group)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int m = m0 + wr * TM + j * 32 + g * 8 + lhi * 4;
+                        if (m >= p.M) continue;
+                        if (m + 3 < p.M && ((p.ldct & 3) == 0)) {
+                            uint2 v;
+                            v.x = pack_bf2(acc[i][j][g * 4 + 0] + bv, acc[i][j][g * 4 + 1] + bv);
+                            v.y = pack_bf2(acc[i][j][g * 4 + 2] + bv, acc[i][j][g * 4 + 3] + bv);
+                            *(uint2*)(row + m) = v;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (m + r < p.M) row[m + r] = f2bf(acc[i][j][g * 4 + r] + bv);
+                        }
+                    }
             }
+        }
         return;
     }
 
     bf16_t* Cb = p.C + (int64_t)bz * p.strideC;
     const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
     if (p.epilogue == TMIX_EPI_GEGLU) {
-        // weight rows are interleaved in 16-row groups [value_j | gate_j]: even fragments hold the
-        // value half, odd fragments the gate half of the same 16 output columns.
+        // weight rows are interleaved in 16-row groups [value_j | gate_j]: within a 32-row fragment, accumulator
+        // register groups g=0,1 (rows 0-15) are the value half and g=2,3 (rows 16-31) the gate half.
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wr * 64 + mi * 16 + fr;
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wr * TM + i * 32 + l31;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj) {
-                const int nv = n0 + wc * 64 + nj * 32 + fg * 4;        // value columns (weight-row index)
-                if (nv >= p.N) continue;
-                const int no = (n0 + wc * 64) / 2 + nj * 16 + fg * 4;  // output column
-                float o[4];
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wc * TN + j * 32;               // weight-row index of this fragment
+                if (nb >= p.N) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = acc[mi][2 * nj][r], g = acc[mi][2 * nj + 1][r];
-                    if (bias) { a += bias[nv + r]; g += bias[nv + 16 + r]; }
-                    o[r] = a * gelu_erf_f(g);
+                for (int g = 0; g < 2; ++g) {
+                    const int nv = nb + g * 8 + lhi * 4;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
+                        if (bias) { a += bias[nv + r]; gt += bias[nv + 16 + r]; }
+                        o[r] = a * gelu_erf_f(gt);
+                    }
+                    uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                    *(uint2*)(Cb + (int64_t)m * p.ldc + nb / 2 + g * 8 + lhi * 4) = v;
                 }
-                uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
-                *(uint2*)(Cb + (int64_t)m * p.ldc + no) = v;
             }
         }
         return;
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wr * 64 + mi * 16 + fr;
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wr * TM + i * 32 + l31;
         if (m >= p.M) continue;
         const float* rg = p.rgb ? p.rgb + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wc * 64 + ni * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float o[4];
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r];
-            if (bias) { const float4 b4 = *(const float4*)(bias + n); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if (rg)   { const float4 b4 = *(const float4*)(rg + n);   o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if (Rb) {
-                const uint2 rv = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
-                o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
-                o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wc * TN + j * 32 + g * 8 + lhi * 4;
+                if (n >= p.N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[i][j][g * 4 + r];
+                if (bias) { const float4 b4 = *(const float4*)(bias + n); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+                if (rg)   { const float4 b4 = *(const float4*)(rg + n);   o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+                if (Rb) {
+                    const uint2 rv = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
+                    o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
+                    o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
+                }
+                uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                *(uint2*)(Cb + (int64_t)m * p.ldc + n) = v;
             }
-            uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
-            *(uint2*)(Cb + (int64_t)m * p.ldc + n) = v;
-        }
     }
 }
 
-template <int CONV>
-int launch(const Params& p, int batch, hipStream_t st) {
+// ------------------------------------------------------------------------------------------- launch
+struct TileCfg { int bm, bn; };
+// cfg ids (tmix.h TMIX_TILE_*): 1 = 128x128 (4 waves, 2 stages, 2 WG/CU), 2 = 256x128 (8 waves, 3 stages),
+// 3 = 128x128 (4 waves, 4 stages, 1 WG/CU), 4 = 256x256 (8 waves, 2 stages)
+constexpr int NUM_CFG = 4;
+__host__ inline TileCfg tile_of(int cfg) {
+    switch (cfg) { case 2: return {256, 128}; case 4: return {256, 256}; default: return {128, 128}; }
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int CONV>
+int launch_cfg(Params& p, int batch, hipStream_t st) {
+    constexpr int SMEM = NS * (BM + BN) * 128;
     static bool attr_set = false;   // idempotent; racing threads set the same value
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_conv_kernel<CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+    p.group_m = BM >= 256 ? 4 : 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
-    gemm_conv_kernel<CONV><<<grid, 256, SMEM_BYTES, st>>>(p);
+    kern<<<grid, WM * WN * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
+}
+
+int pick_cfg(const Params& p, int batch) {
+    // heuristic default (the plan builder can override per shape after timing the candidates):
+    // 256x128 when it still yields >= 3/4 of a CU wave, else 128x128.
+    const int64_t t2 = (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
+    return t2 >= 192 ? 2 : 1;
+}
+
+template <int CONV>
+int launch(Params& p, int batch, int cfg, hipStream_t st) {
+    if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
+    if (cfg == 4 && p.n_trans_begin >= 0) cfg = 2;   // transposed stores need square wave tiles
+    switch (cfg) {
+    case 1: return launch_cfg<128, 128, 2, 2, 2, CONV>(p, batch, st);
+    case 2: return launch_cfg<256, 128, 4, 2, 3, CONV>(p, batch, st);
+    case 3: return launch_cfg<128, 128, 2, 2, 4, CONV>(p, batch, st);
+    default: return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
+    }
 }
 
 }  // namespace
@@ -259,7 +346,7 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     if ((d->lda % 8) || (d->ldw % 8) || (d->strideA % 8) || (d->strideW % 8)) TMIX_FAIL(TMIX_EALIGN, "gemm: lda/ldw/strides must be multiples of 8 elements");
     if (!aligned16(d->A) || !aligned16(d->W)) TMIX_FAIL(TMIX_EALIGN, "gemm: A/W must be 16-byte aligned");
     const bool has_trans = d->n_trans_begin >= 0 && d->n_trans_begin < d->N;
-    if (has_trans && (!d->Ct || (d->n_trans_begin % BN))) TMIX_FAIL(TMIX_EINVAL, "gemm: transposed region needs Ct and n_trans_begin %% %d == 0", BN);
+    if (has_trans && (!d->Ct || (d->n_trans_begin % 128))) TMIX_FAIL(TMIX_EINVAL, "gemm: transposed region needs Ct and n_trans_begin %% 128 == 0");
     if ((!has_trans || d->n_trans_begin > 0) && !d->C) TMIX_FAIL(TMIX_EINVAL, "gemm: null C");
     if (d->C && ((d->ldc % 4) || (((uintptr_t)d->C) & 7) || (d->strideC % 4))) TMIX_FAIL(TMIX_EALIGN, "gemm: C must be 8-byte aligned with ldc %% 4 == 0");
     if (d->residual && ((d->ldr % 4) || (((uintptr_t)d->residual) & 7))) TMIX_FAIL(TMIX_EALIGN, "gemm: residual alignment");
@@ -277,9 +364,8 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     p.Ct = (bf16_t*)d->Ct; p.ldct = d->ldct; p.strideCt = d->strideCt;
     p.n_trans_begin = has_trans ? d->n_trans_begin : -1;
     p.M = d->M; p.N = d->N; p.K = d->K;
-    p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
     p.epilogue = d->epilogue;
-    return launch<0>(p, d->batch, (hipStream_t)stream);
+    return launch<0>(p, d->batch, d->tile_cfg, (hipStream_t)stream);
 }
 
 extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
@@ -305,7 +391,6 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.rgb = d->batch_bias; p.rows_per_group = p.Ho * p.Wo;
     p.n_trans_begin = -1;
     p.M = (int)M; p.N = d->Cout; p.K = 9 * d->Cin;
-    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
     p.epilogue = TMIX_EPI_NONE;
-    return launch<1>(p, 1, (hipStream_t)stream);
+    return launch<1>(p, 1, d->tile_cfg, (hipStream_t)stream);
 }

@@ -15,6 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
 CONV_S1, CONV_S2, CONV_UP2 = 0, 1, 2
+TILE_AUTO, TILE_COUNT = 0, 4
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -30,13 +31,13 @@ class GemmDesc(C.Structure):
                 ("Ct", vp), ("ldct", i64), ("strideCt", i64),
                 ("n_trans_begin", i32),
                 ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
-                ("epilogue", i32)]
+                ("epilogue", i32), ("tile_cfg", i32)]
 
 
 class ConvDesc(C.Structure):
     """mirror of tmix_conv_desc"""
     _fields_ = [("X", vp), ("Wt", vp), ("Y", vp), ("bias", vp), ("batch_bias", vp), ("residual", vp),
-                ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("mode", i32)]
+                ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("mode", i32), ("tile_cfg", i32)]
 
 
 SIGNATURES = {

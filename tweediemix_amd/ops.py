@@ -62,7 +62,7 @@ def fused_tweedie_step(x, eps, masks, mode, K, g, at, at_next, is_last=False, ou
 
 
 def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows_per_group=0, geglu=False,
-                   out_t=None, n_trans_begin=-1):
+                   out_t=None, n_trans_begin=-1, tile_cfg=0):
     """a [batch?,M,K] bf16 (last dim contiguous), w [batch?,N,K] bf16, out [batch?,M,N'] bf16."""
     a3 = a if a.dim() == 3 else a.unsqueeze(0)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -96,6 +96,7 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
         d.n_trans_begin = n_trans_begin
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.epilogue = L.EPI_GEGLU if geglu else L.EPI_NONE
+    d.tile_cfg = tile_cfg
     return d
 
 
@@ -114,7 +115,7 @@ def gemm(a, w, out=None, **kw):
     return out
 
 
-def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1):
+def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0):
     """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -124,6 +125,7 @@ def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.
     d.X, d.Wt, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.batch_bias, d.residual = _p(bias), _p(batch_bias), _p(residual)
     d.B, d.H, d.W, d.Cin, d.Cout, d.mode = B, H, W, Cin, Cout, mode
+    d.tile_cfg = tile_cfg
     return d
 
 
@@ -131,14 +133,14 @@ def conv_out_hw(H, W, mode):
     return (H // 2, W // 2) if mode == L.CONV_S2 else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
 
 
-def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None):
+def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0):
     _need_cuda(x, w)
     lib = L.load()
     B, H, W, _ = x.shape
     Ho, Wo = conv_out_hw(H, W, mode)
     if out is None:
         out = torch.empty(B, Ho, Wo, w.shape[0], device=x.device, dtype=BF16)
-    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode)
+    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode, tile_cfg)
     L.check(lib.tmix_conv3x3_nhwc(C.byref(d), _stream()), "tmix_conv3x3_nhwc")
     return out
 

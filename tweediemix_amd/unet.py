@@ -223,6 +223,20 @@ class _Arena:
             self.free.setdefault(buf.numel(), []).append(buf)
 
 
+_TUNE_CACHE = {}      # (kind, shape key) -> best TMIX_TILE_* id, shared by every plan in the process
+
+
+def _time_launch(fn, desc, stream, reps=4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(C.byref(desc), stream)
+    e0.record()
+    for _ in range(reps):
+        fn(C.byref(desc), stream)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 class UNetPlan:
     """One UNet call shape: batch B, latent h x w, a KV cache (prompt rows) and a routing flag.
 
@@ -231,7 +245,7 @@ class UNetPlan:
     """
 
     def __init__(self, W: UNetWeights, B: int, h: int, w: int, kv: KVCache, pooled: torch.Tensor,
-                 time_ids: torch.Tensor, routed: bool = False):
+                 time_ids: torch.Tensor, routed: bool = False, autotune: bool = True):
         self.W, self.cfg, self.B, self.h, self.w = W, W.cfg, B, h, w
         self.kv = kv
         self.routed = bool(routed) and W.kind == "lora" and B == W.K + 1
@@ -258,6 +272,30 @@ class UNetPlan:
         self._gn_ws = torch.empty(B * 128 * cfg.norm_groups * 2, device=dev, dtype=F32)
         self._vt = {}
         self._build()
+        if autotune:
+            self.autotune()
+
+    def autotune(self):
+        """pick the fastest workgroup tiling (TMIX_TILE_*) per distinct GEMM / conv shape by timing the
+        candidates on the device (the shapes of this path are small and awkward -- M=4096, N=1280 -- so
+        tile quantisation over 256 CUs, not peak MFMA rate, decides).  Descriptors are patched in place."""
+        st = torch.cuda.current_stream().cuda_stream
+        for kind, fn in (("gemm", self.lib.tmix_gemm_bf16), ("conv", self.lib.tmix_conv3x3_nhwc)):
+            for d, _fl in self.launches[kind]:
+                if kind == "gemm":
+                    key = (kind, d.M, d.N, d.K, d.batch, d.epilogue, d.n_trans_begin >= 0, bool(d.residual), d.strideW != 0)
+                else:
+                    key = (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode)
+                best = _TUNE_CACHE.get(key)
+                if best is None:
+                    times = {}
+                    for cfg in range(1, L.TILE_COUNT + 1):
+                        d.tile_cfg = cfg
+                        times[cfg] = _time_launch(fn, d, st)
+                    best = min(times, key=times.get)
+                    _TUNE_CACHE[key] = best
+                d.tile_cfg = best
+        torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ op emitters
     def _emit(self, fn, *args):
