@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (debug only; not a valid bench line)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="independent launch chains per UNet call (rows split over HIP streams)")
+    ap.add_argument("--seeds-per-gpu", type=int, default=1,
+                    help="independent trajectories co-batched into every UNet launch (1 = the reference's one image per process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--cpu-rows", type=int, default=1, help="batch rows of one fusion step timed on the CPU")
@@ -57,9 +60,13 @@ def build_sampler(args, device, seed):
     conf = S.make_config(guidance_scale=0.8, n_timesteps=50, t_cond=0.2, t_stop=0.8, resampling_steps=10,
                          jumping_steps=5, resolution_h=args.res, resolution_w=args.res, seed=seed)
     tw = S.Tweediemix(conf, W, te, ts, lambda x0: M.build_masks(imgs, h, w, device), concept_num=K,
-                      lora=(args.kind == "lora"), use_graphs=not args.no_graphs)
+                      lora=(args.kind == "lora"), use_graphs=not args.no_graphs, n_seeds=args.seeds_per_gpu,
+                      n_streams=args.streams)
     tw.init_fusion(int(50 * 0.2), int(50 * 0.8)) if args.kind == "lora" else tw.init_fusion(int(50 * 0.2))
     tw.masks = M.build_masks(imgs, h, w, device)
+    if args.seeds_per_gpu > 1:
+        tw.masks = torch.stack([M.build_masks(M.random_rectangle_masks(K, args.res, args.res, seed=1000 * seed + i), h, w, device)
+                                for i in range(args.seeds_per_gpu)]).contiguous()
     return tw, (sd, con, te, ts, cfg)
 
 
@@ -78,6 +85,8 @@ def gemm_roofline(plan):
     ev = {"gemm": [], "conv": [], "attn": []}
     plan.run()
     torch.cuda.synchronize()
+    if hasattr(plan, "plans"):          # PlanGroup: the instrumented pass runs the sub-plans back to back on one stream
+        pass
     for fn, a in plan.ops:
         key = "gemm" if fn is gemm_fn else "conv" if fn is conv_fn else "attn" if fn is attn_fn else None
         if key:
@@ -154,13 +163,14 @@ def main():
     plan = tw.plan("fusion")
     fusion_ts = [t for t in tw.scheduler.timesteps if t <= tw.t_cond_cur and t in tw._window]
     seed_gen = torch.Generator().manual_seed(1000 + rank)
-    x = torch.randn(1, 4, tw.h, tw.w, generator=seed_gen).to(device)
+    S = args.seeds_per_gpu
+    x = torch.randn(S, 4, tw.h, tw.w, generator=seed_gen).to(device)
 
     def step(i, x):
+        from tweediemix_amd import lib as L
         t = fusion_ts[i % len(fusion_ts)]
         eps = tw._unet("fusion", x, t)
-        from tweediemix_amd import lib as L, ops
-        return ops.fused_tweedie_step(x, eps, tw.masks, L.STEP_FUSION, K, 0.8, tw.alpha(t), tw.alpha(t - tw.skip))
+        return tw._step(x, eps, L.STEP_FUSION, tw.alpha(t), tw.alpha(t - tw.skip))
 
     for i in range(args.warmup):
         x = step(i, x)
@@ -181,7 +191,7 @@ def main():
         from tweediemix_amd import dist as D
         dt = D.max_over_ranks(dt, device)
         # result gather (the only collective on this path): final latents of every rank's seeds
-        gathered = D.gather_latents(x.contiguous(), world, rank, world)
+        gathered = D.gather_latents(x[:1].contiguous(), world, rank, world)
         assert gathered.shape[0] == world and torch.isfinite(gathered).all()
 
     if rank == 0:
@@ -189,14 +199,14 @@ def main():
         g = roof["gemm"]
         line = {
             "metric": "denoise steps/sec @ SDXL 1024^2 K=3 concepts (fusion phase)",
-            "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "value": world * S * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / (args.steps * S), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base UNet shapes, {args.res}x{args.res}, K=3 concepts ({args.kind} deltas), "
                                    f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel"
                                    + (" [TINY DEBUG CONFIG]" if args.tiny else ""),
-                       "seeds_per_gpu": 1, "hip_graph": not args.no_graphs, "parallelism": f"replicas x{world} (seed-sharded)"},
-            "unet_tflop_per_step": plan.flops / 1e12,
+                       "seeds_per_gpu": S, "streams": args.streams, "hip_graph": not args.no_graphs, "parallelism": f"replicas x{world} (seed-sharded)"},
+            "unet_tflop_per_step": plan.flops / 1e12 / S,
             "achieved_tflops_whole_step": plan.flops / 1e12 / (dt / args.steps),
             "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<0> (tmix_gemm_bf16)", "achieved": g["tflops"],
                          "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,

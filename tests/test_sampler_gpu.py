@@ -171,3 +171,33 @@ def test_end_to_end_vs_oracle_sampler(kind, graphs):
         print(f"   t={t} rel={r:.4g}")
         # the start step holds 1 + 2*resampling UNet calls and divides by sqrt(alpha_981) ~ 0.07
         assert r <= (6e-2 if int(t) == tw.start_t else 2e-2), (t, r)
+
+
+def test_two_seeds_co_batched_equal_independent_runs():
+    """n_seeds=2 shares every UNet launch between two trajectories; each must match its own single-seed run
+    (rows of different seeds never interact: attention is per batch row, norms are per sample)."""
+    need_gpu()
+    from tweediemix_amd import masks as M, sampler as S
+    K, n, h, w = 3, 10, 16, 16
+    for kind in ("custom", "lora"):
+        _orc, W, te, ts = _tiny_setup(kind, K, n, h, w)
+        cfg = S.make_config(guidance_scale=0.8, n_timesteps=n, t_cond=0.2, t_stop=0.8, resampling_steps=1, jumping_steps=1,
+                            resolution_h=h * 8, resolution_w=w * 8)
+        imgs = [M.random_rectangle_masks(K, h * 8, w * 8, seed=s) for s in (3, 4)]
+        torch.manual_seed(7)
+        xT = torch.randn(2, 4, h, w)
+        singles = []
+        for i in range(2):
+            tw = S.Tweediemix(cfg, W, te, ts, lambda x0, i=i: M.build_masks(imgs[i], h, w), concept_num=K, lora=(kind == "lora"))
+            singles.append(tw.run_fusion(xT[i:i + 1].clone()).cpu())
+        calls = {"n": 0}
+
+        def provider(x0):
+            i = calls["n"] % 2
+            calls["n"] += 1
+            return M.build_masks(imgs[i], h, w)
+        tw2 = S.Tweediemix(cfg, W, te, ts, provider, concept_num=K, lora=(kind == "lora"), n_seeds=2)
+        both = tw2.run_fusion(xT.clone()).cpu()
+        for i in range(2):
+            torch.testing.assert_close(both[i:i + 1], singles[i], rtol=1e-3, atol=1e-3)
+        assert tw2.plan("fusion").B == 8 and [c[1] for c in tw2.unet_calls][:1] == [4]

@@ -12,7 +12,7 @@
 //   * v_mfma_f32_32x32x16_bf16, wave tile (BM/WM) x (BN/WN), fp32 accumulation;
 //   * the convolution differs only in how a lane finds its source address (im2col on the fly: K-tile kt
 //     is tap kt / (Cin/64), channels (kt % (Cin/64))*64..+63 of the shifted pixel; padding taps read a
-//     zero page); stride-2 and nearest-x2 upsampling are folded into the gather;
+//     zeros via the buffer bounds check); stride-2 and nearest-x2 upsampling are folded into the gather;
 //   * fused epilogues: bias, per-row-group bias (time embedding), residual add, GEGLU, transposed store
 //     (V^T for the attention kernel), per-batch weight sets (concept routing).
 //
@@ -24,8 +24,6 @@ namespace {
 constexpr int BK = 64;
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // 256 B of zeros (conv padding taps)
-
 struct Params {
     const bf16_t* A; int64_t lda, strideA;
     const bf16_t* W; int64_t ldw, strideW;
@@ -35,13 +33,16 @@ struct Params {
     const float* rgb; int rows_per_group;
     bf16_t* Ct; int64_t ldct, strideCt; int n_trans_begin;
     int M, N, K, tiles_m, tiles_n, group_m, epilogue;
+    unsigned bytesA, bytesW;          // extents of one batch slice (buffer bounds)
     // convolution geometry (CONV only)
     int H, Wd, Cin, Ho, Wo, mode;
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
+// address is ONE 32-bit VGPR that stays constant across K-tiles (the K advance rides in the scalar soffset), and
+// out-of-range offsets read as zero, which is how convolution padding taps are produced (no zero page, no selects).
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -78,18 +79,20 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_conv_kernel(const Params p)
 
     const bf16_t* Ab = p.A + (int64_t)bz * p.strideA;
     const bf16_t* Wb = p.W + (int64_t)bz * p.strideW;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, p.bytesW, 0x00020000);
 
     // ---- per-lane staging sources. Wave-instruction idx = r*NW + w covers LDS rows idx*8 .. idx*8+7.
     const int lrow = lane >> 3;
-    const bf16_t* wsrc[RB];
-    const bf16_t* asrc[RA];
+    // per-lane offsets are 32-bit element counts off wave-uniform bases (saddr + voffset form of global_load_lds)
+    unsigned woff[RB], aoff[RA];
     int pb[RA], py[RA], px[RA], asw[RA];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int idx = r * NW + w;
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
         int n = n0 + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
-        wsrc[r] = Wb + (int64_t)n * p.ldw + sw;
+        woff[r] = ((unsigned)n * (unsigned)p.ldw + sw) * 2u;
     }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
@@ -101,9 +104,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_conv_kernel(const Params p)
             const int hw = p.Ho * p.Wo;
             pb[r] = m / hw; const int rem = m - pb[r] * hw;
             py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
-            asrc[r] = nullptr;
+            aoff[r] = 0;
         } else {
-            asrc[r] = Ab + (int64_t)m * p.lda + sw;
+            aoff[r] = ((unsigned)m * (unsigned)p.lda + sw) * 2u;
         }
     }
 
@@ -118,22 +121,21 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_conv_kernel(const Params p)
         if constexpr (CONV) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            const bf16_t* ga;
             if constexpr (CONV) {
                 int iy, ix; bool ok;
                 if (p.mode == TMIX_CONV_S1)      { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
                 else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
                 else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
                        ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
-                ga = ok ? Ab + ((int64_t)(pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + cc * BK + asw[r]
-                        : (const bf16_t*)g_zero_page + asw[r];
+                const unsigned vo = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + cc * BK + asw[r]) * 2u
+                                       : 0xfffffff0u;               // beyond num_records -> zeros (padding)
+                blds16(rsA, vo, 0u, sA + (r * NW + w) * 1024);
             } else {
-                ga = asrc[r] + (int64_t)kt * BK;
+                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + (r * NW + w) * 1024);
             }
-            glds16(ga, sA + (r * NW + w) * 1024);
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) glds16(wsrc[r] + (int64_t)kt * BK, sW + (r * NW + w) * 1024);
+        for (int r = 0; r < RB; ++r) blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + (r * NW + w) * 1024);
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; } }
     };
 
@@ -354,6 +356,7 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     if (d->rowgroup_bias && (d->rows_per_group <= 0 || (((uintptr_t)d->rowgroup_bias) & 15))) TMIX_FAIL(TMIX_EINVAL, "gemm: rowgroup_bias needs rows_per_group > 0 and 16-byte alignment");
     if (d->epilogue == TMIX_EPI_GEGLU && ((d->N % 32) || has_trans || d->residual || d->rowgroup_bias)) TMIX_FAIL(TMIX_EINVAL, "gemm: GEGLU needs N %% 32 == 0 and no residual/transposed region");
     if (d->epilogue != TMIX_EPI_NONE && d->epilogue != TMIX_EPI_GEGLU) TMIX_FAIL(TMIX_EINVAL, "gemm: bad epilogue %d", d->epilogue);
+    if ((int64_t)d->M * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldw >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm: operand extent exceeds 32-bit element offsets");
     Params p = {};
     p.A = (const bf16_t*)d->A; p.lda = d->lda; p.strideA = d->strideA;
     p.W = (const bf16_t*)d->W; p.ldw = d->ldw; p.strideW = d->strideW;
@@ -365,6 +368,8 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     p.n_trans_begin = has_trans ? d->n_trans_begin : -1;
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.epilogue = d->epilogue;
+    p.bytesA = (unsigned)(((int64_t)(d->M - 1) * d->lda + d->K) * 2);
+    p.bytesW = (unsigned)(((int64_t)(d->N - 1) * d->ldw + d->K) * 2);
     return launch<0>(p, d->batch, d->tile_cfg, (hipStream_t)stream);
 }
 
@@ -383,6 +388,7 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.Wo = d->mode == TMIX_CONV_S2 ? d->W / 2 : (d->mode == TMIX_CONV_UP2 ? d->W * 2 : d->W);
     const int64_t M = (int64_t)d->B * p.Ho * p.Wo;
     if (M > 0x7fffffff / 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: too many output pixels");
+    if ((int64_t)d->B * d->H * d->W * d->Cin >= (1ll << 31) || (int64_t)d->Cout * 9 * d->Cin >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: operand extent exceeds 32-bit element offsets");
     p.A = (const bf16_t*)d->X;
     p.W = (const bf16_t*)d->Wt; p.ldw = 9 * (int64_t)d->Cin;
     p.C = (bf16_t*)d->Y; p.ldc = d->Cout;
@@ -392,5 +398,7 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.n_trans_begin = -1;
     p.M = (int)M; p.N = d->Cout; p.K = 9 * d->Cin;
     p.epilogue = TMIX_EPI_NONE;
+    p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
+    p.bytesW = (unsigned)((int64_t)d->Cout * 9 * d->Cin * 2);
     return launch<1>(p, 1, d->tile_cfg, (hipStream_t)stream);
 }

@@ -23,7 +23,7 @@ import torch
 from . import lib as L
 from . import ops
 from .schedule import Schedule
-from .unet import KVCache, UNetPlan, UNetWeights
+from .unet import KVCache, PlanGroup, UNetPlan, UNetWeights
 
 F32 = torch.float32
 
@@ -65,7 +65,8 @@ class Tweediemix:
     """
 
     def __init__(self, config, weights: UNetWeights, text_embeds, text_embeds_single, mask_provider,
-                 concept_num: int, lora: bool = False, strict_reference: bool = True, use_graphs: bool = False):
+                 concept_num: int, lora: bool = False, strict_reference: bool = True, use_graphs: bool = False,
+                 n_seeds: int = 1, n_streams: int = 1):
         self.config = config
         self.W = weights
         self.device = weights.device
@@ -73,6 +74,11 @@ class Tweediemix:
         self.lora = bool(lora)
         self.strict_reference = strict_reference
         self.use_graphs = use_graphs
+        # n_seeds independent trajectories share every UNet launch (rows [seed][uncond, concepts...]); the
+        # reference runs one seed per process -- co-batching only raises the GEMM M dimension.
+        self.n_seeds = int(n_seeds)
+        # n_streams > 1 splits the rows of every UNet call into that many independent launch chains (PlanGroup)
+        self.n_streams = int(n_streams)
         self.text_embeds = text_embeds
         self.text_embeds_single = text_embeds_single
         self.mask_provider = mask_provider
@@ -89,7 +95,7 @@ class Tweediemix:
         self.graphs = {}
         self.unet_calls = []          # (kind, B, t) trace, for tests / accounting
         self.preview_x0 = None
-        self._bufs = [torch.empty(1, 4, self.h, self.w, device=self.device, dtype=F32) for _ in range(3)]
+        self._bufs = [torch.empty(self.n_seeds, 4, self.h, self.w, device=self.device, dtype=F32) for _ in range(3)]
 
     # ------------------------------------------------------------------ schedule
     def alpha(self, t):
@@ -116,9 +122,16 @@ class Tweediemix:
             ehs, pooled, routed, wsel = te[0:2], tp[0:2], False, [0, 0]
         else:
             raise ValueError(kind)
+        S = self.n_seeds
+        if S > 1:                                     # seed-major rows: b = seed * rows_per_seed + row
+            ehs, pooled, wsel = ehs.repeat(S, 1, 1), pooled.repeat(S, 1), list(wsel) * S
         B = ehs.shape[0]
+        if self.n_streams > 1 and B % self.n_streams == 0:
+            return PlanGroup(self.W, self.h, self.w, ehs, wsel, pooled, self.add_time_ids.repeat(B, 1), routed,
+                             self.n_streams)
         kv = KVCache(self.W, ehs, wsel)
-        return UNetPlan(self.W, B, self.h, self.w, kv, pooled, self.add_time_ids.repeat(B, 1), routed=routed)
+        return UNetPlan(self.W, B, self.h, self.w, kv, pooled, self.add_time_ids.repeat(B, 1), routed=routed,
+                        row_sets=wsel if routed else None)
 
     def plan(self, kind):
         if kind not in self.plans:
@@ -126,10 +139,12 @@ class Tweediemix:
         return self.plans[kind]
 
     def _unet(self, kind, x, t):
-        """eps [B,4,h,w] fp32 for the call kind's prompt rows; x is broadcast over the batch."""
+        """eps [n_seeds*rows,4,h,w] fp32 for the call kind's prompt rows; each seed's latent is broadcast over
+        its rows."""
         p = self.plan(kind)
-        self.unet_calls.append((kind, p.B, int(t)))
-        p.latent.copy_(x.expand(p.B, -1, -1, -1))
+        S = self.n_seeds
+        self.unet_calls.append((kind, p.B // S, int(t)))
+        p.latent.view(S, p.B // S, *p.latent.shape[1:]).copy_(x.unsqueeze(1))
         p.t_dev.fill_(float(t))
         if self.use_graphs:
             g = self.graphs.get(kind)
@@ -166,12 +181,23 @@ class Tweediemix:
         return t <= self.t_cond_cur
 
     def _step(self, x, eps, mode, at, at_next, is_last=False, out=None, out_x0=None):
-        return ops.fused_tweedie_step(x, eps, self.masks if mode == L.STEP_FUSION else None, mode, self.concept_num,
-                                      self.config.guidance_scale, at, at_next, is_last, out_x=out, out_x0=out_x0)
+        """fused CFG/Tweedie/blend/DDIM for every seed (one launch per seed; eps rows of a seed are contiguous)."""
+        S = self.n_seeds
+        if out is None:
+            out = torch.empty_like(x)
+        rows = eps.shape[0] // S
+        for sd in range(S):
+            m = None
+            if mode == L.STEP_FUSION:
+                m = self.masks if S == 1 else self.masks[sd]
+            ops.fused_tweedie_step(x[sd:sd + 1], eps[sd * rows:(sd + 1) * rows], m, mode, self.concept_num,
+                                   self.config.guidance_scale, at, at_next, is_last, out_x=out[sd:sd + 1],
+                                   out_x0=None if out_x0 is None else out_x0[sd:sd + 1])
+        return out
 
     @torch.no_grad()
     def denoise_step(self, x, t):
-        """x [1,4,h,w] fp32 on the device, t python int (or 0-dim tensor). Returns the next latent."""
+        """x [n_seeds,4,h,w] fp32 on the device, t python int (or 0-dim tensor). Returns the next latent(s)."""
         t = int(t)
         cfg = self.config
         next_t = t - self.skip
@@ -203,8 +229,12 @@ class Tweediemix:
                 x0j = torch.empty_like(out)
                 xt = self._step(xt, eps_j, L.STEP_PLAIN, a_t, self.alpha(tt), out_x0=x0j)
             self.preview_x0 = x0j.clone()
-            self.masks = self.mask_provider(self.preview_x0).to(self.device, F32).contiguous()
-            assert self.masks.shape[0] == self.concept_num
+            if self.n_seeds == 1:
+                self.masks = self.mask_provider(self.preview_x0).to(self.device, F32).contiguous()
+                assert self.masks.shape[0] == self.concept_num
+            else:                                     # one mask set per seed: [n_seeds, K, 1, h, w]
+                self.masks = torch.stack([self.mask_provider(self.preview_x0[i:i + 1]).to(self.device, F32)
+                                          for i in range(self.n_seeds)]).contiguous()
         return out
 
     def run_fusion(self, x=None):
@@ -215,7 +245,7 @@ class Tweediemix:
         else:
             self.init_fusion(t_cond)
         if x is None:      # drawn on the CPU like the reference (fusion_sampling.py:488): device-independent seeds
-            x = torch.randn(1, 4, self.h, self.w) * self.scheduler.init_noise_sigma
+            x = torch.randn(self.n_seeds, 4, self.h, self.w) * self.scheduler.init_noise_sigma
         return self.sample_loop(x.to(self.device, F32))
 
     @torch.no_grad()

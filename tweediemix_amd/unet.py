@@ -245,10 +245,14 @@ class UNetPlan:
     """
 
     def __init__(self, W: UNetWeights, B: int, h: int, w: int, kv: KVCache, pooled: torch.Tensor,
-                 time_ids: torch.Tensor, routed: bool = False, autotune: bool = True):
+                 time_ids: torch.Tensor, routed: bool = False, autotune: bool = True, row_sets=None,
+                 latent=None, eps=None):
         self.W, self.cfg, self.B, self.h, self.w = W, W.cfg, B, h, w
         self.kv = kv
-        self.routed = bool(routed) and W.kind == "lora" and B == W.K + 1
+        # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
+        self.row_sets = list(row_sets) if row_sets is not None else list(range(B))
+        self.routed = bool(routed) and W.kind == "lora" and len(self.row_sets) == B and max(self.row_sets) <= W.K
+        self._rows_cache = {}
         self.lib = L.load()
         self.dev = W.device
         self.ops = []
@@ -260,9 +264,11 @@ class UNetPlan:
         cfg = self.cfg
         assert kv.B == B
         dev = self.dev
-        self.latent = torch.zeros(B, cfg.in_channels, h, w, device=dev, dtype=F32)
+        # I/O buffers may be views into a larger batch owned by a PlanGroup (row-split execution on several streams)
+        self.latent = latent if latent is not None else torch.zeros(B, cfg.in_channels, h, w, device=dev, dtype=F32)
         self.t_dev = torch.zeros(B, device=dev, dtype=F32)
-        self.eps = torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
+        self.eps = eps if eps is not None else torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
+        assert self.latent.is_contiguous() and self.eps.is_contiguous() and self.latent.shape[0] == B
         # static conditioning: aug_emb = add_embedding(cat[pooled, sinusoid(time_ids)])  (depends on rows only)
         tid = ops.timestep_embedding(time_ids.to(dev, F32).reshape(-1).contiguous(), cfg.addition_time_embed_dim)
         add_in = torch.cat([pooled.to(dev, F32), tid.reshape(B, -1)], dim=-1).contiguous()
@@ -381,7 +387,7 @@ class UNetPlan:
         """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM."""
         W = self.W
         if self.routed:
-            return self._gemm(a.view(self.B, S, Cin), W[key + "_rows"], out, **kw)
+            return self._gemm(a.view(self.B, S, Cin), self._rows(key), out, **kw)
         o2 = out.view(self.B * S, out.shape[-1]) if out is not None else None
         for kk in ("residual",):
             if kw.get(kk) is not None:
@@ -389,6 +395,15 @@ class UNetPlan:
         if kw.get("out_t") is not None:       # transposed V is per batch row -> keep the batch dimension
             return self._gemm(a.view(self.B, S, Cin), W[key], out, **kw)
         return self._gemm(a.view(self.B * S, Cin), W[key], o2, **kw)
+
+    def _rows(self, key):
+        """[B, N, K] per-row weight sets for a routed projection (a view when rows are 0..K in order)."""
+        w = self.W[key + "_rows"]
+        if self.row_sets == list(range(w.shape[0])):
+            return w
+        if key not in self._rows_cache:
+            self._rows_cache[key] = w[torch.tensor(self.row_sets, device=w.device)].contiguous()
+        return self._rows_cache[key]
 
     def _t2d(self, x, Cc, Hh, Ww, name, n):
         B, W, A = self.B, self.W, self.arena
@@ -523,3 +538,60 @@ class UNetPlan:
         self.t_dev.fill_(float(t))
         self.run()
         return self.eps
+
+
+class PlanGroup:
+    """The batch rows of one UNet call split into `n_groups` independent sub-plans, each enqueued on its own HIP
+    stream (rows never interact inside the UNet).  Dependent launches of one chain leave the chip partly idle at
+    every kernel boundary (tail of one GEMM, launch gap, cold first loads of the next: ~10 us per launch against
+    30-150 us kernels); two or more independent chains in flight let the hardware fill those holes with the other
+    chain's workgroups.  Presents the same interface as a UNetPlan (latent, t_dev.fill_, eps, run, B, flops)."""
+
+    def __init__(self, W: UNetWeights, h: int, w: int, ehs: torch.Tensor, wsel, pooled: torch.Tensor,
+                 time_ids: torch.Tensor, routed: bool, n_groups: int):
+        B = ehs.shape[0]
+        assert B % n_groups == 0
+        self.B, self.n_groups = B, n_groups
+        dev = W.device
+        cfg = W.cfg
+        self.latent = torch.zeros(B, cfg.in_channels, h, w, device=dev, dtype=F32)
+        self.eps = torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
+        per = B // n_groups
+        self.plans, self.streams = [], []
+        for g in range(n_groups):
+            sl = slice(g * per, (g + 1) * per)
+            kv = KVCache(W, ehs[sl], list(wsel)[sl])
+            self.plans.append(UNetPlan(W, per, h, w, kv, pooled[sl], time_ids[sl], routed=routed,
+                                       row_sets=list(wsel)[sl] if routed else None,
+                                       latent=self.latent[sl], eps=self.eps[sl]))
+            self.streams.append(torch.cuda.Stream(device=dev) if g > 0 else None)
+        self.t_dev = _FillAll([p.t_dev for p in self.plans])
+        self.flops = sum(p.flops for p in self.plans)
+        self.gemm_flops = sum(p.gemm_flops for p in self.plans)
+        self.launches = {k: [x for p in self.plans for x in p.launches[k]] for k in ("gemm", "conv", "attn")}
+        self.ops = [op for p in self.plans for op in p.ops]
+
+    def run(self):
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for p, st in zip(self.plans[1:], self.streams[1:]):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                p.run()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                joins.append(ev)
+        self.plans[0].run()
+        for ev in joins:
+            main.wait_event(ev)
+
+
+class _FillAll:
+    def __init__(self, ts):
+        self.ts = ts
+
+    def fill_(self, v):
+        for t in self.ts:
+            t.fill_(v)
