@@ -114,3 +114,30 @@ def test_lora_merged_rows():
             ref = sd[f"{a1}.to_{nm}.weight"] + con[i][f"{a1}.processor.to_{nm}_lora.up.weight"] @ con[i][f"{a1}.processor.to_{nm}_lora.down.weight"]
             torch.testing.assert_close(rows[i + 1, j * Cc:(j + 1) * Cc], ref, rtol=2 ** -7, atol=1e-3)
     torch.testing.assert_close(rows[0, :Cc], sd[f"{a1}.to_q.weight"], rtol=2 ** -7, atol=1e-3)
+
+
+def test_plan_group_row_split_matches_single_plan():
+    """PlanGroup (rows split over HIP streams) must give exactly the rows a single plan gives."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tweediemix_amd import unet as U, weights as Wt
+    cfg = U.TINY
+    sd = Wt.synthetic_state_dict(cfg, seed=1234, nontrivial=True)
+    con = Wt.synthetic_concepts(cfg, "lora", 3)
+    W = U.UNetWeights(cfg, sd, "cuda", ("lora", con))
+    g = torch.Generator().manual_seed(2)
+    B, h, w = 4, 16, 16
+    ehs = torch.randn(B, 77, cfg.cross_dim, generator=g)
+    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]] * B)
+    x = torch.randn(B, 4, h, w, generator=g).cuda()
+    wsel = [0, 1, 2, 3]
+    one = U.UNetPlan(W, B, h, w, U.KVCache(W, ehs, wsel), pooled, tid, routed=True, row_sets=wsel)
+    ref = one(x, 500).clone()
+    for ng in (2, 4):
+        grp = U.PlanGroup(W, h, w, ehs, wsel, pooled, tid, True, ng)
+        grp.latent.copy_(x)
+        grp.t_dev.fill_(500.0)
+        grp.run()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(grp.eps, ref, rtol=1e-3, atol=1e-3)

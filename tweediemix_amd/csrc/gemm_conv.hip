@@ -48,7 +48,8 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV>
-__global__ void __launch_bounds__(WM * WN * 64) gemm_conv_kernel(const Params p) {
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
+gemm_conv_kernel(const Params p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
     constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
@@ -296,10 +297,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_conv_kernel(const Params p)
 struct TileCfg { int bm, bn; };
 // cfg ids (tmix.h TMIX_TILE_*): 1 = 128x128 (4 waves, 2 stages, 2 WG/CU), 2 = 256x128 (8 waves, 3 stages),
 // 3 = 128x128 (4 waves, 4 stages, 1 WG/CU), 4 = 256x256 (8 waves, 2 stages)
-constexpr int NUM_CFG = 4;
-__host__ inline TileCfg tile_of(int cfg) {
-    switch (cfg) { case 2: return {256, 128}; case 4: return {256, 256}; default: return {128, 128}; }
-}
+// 5 = 256x128 (4 waves of 128x64, 3 stages, 1 WG/CU), 6 = 256x256 (4 waves of 128x128, 2 stages, 1 WG/CU):
+// one wave per SIMD with a large register tile -- on this chip instructions of co-resident waves do not overlap on a
+// SIMD, so MFMA utilisation is set by MFMAs per non-MFMA instruction, i.e. by the wave tile.
+constexpr int NUM_CFG = 6;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -313,6 +314,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     }
     p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
     p.group_m = BM >= 256 ? 4 : 8;
+    if (BM >= 256 && BN >= 256) p.group_m = 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     kern<<<grid, WM * WN * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
@@ -329,12 +331,14 @@ int pick_cfg(const Params& p, int batch) {
 template <int CONV>
 int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
-    if (cfg == 4 && p.n_trans_begin >= 0) cfg = 2;   // transposed stores need square wave tiles
+    if ((cfg == 4 || cfg == 5) && p.n_trans_begin >= 0) cfg = 2;   // transposed stores need square wave tiles
     switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 2, CONV>(p, batch, st);
     case 2: return launch_cfg<256, 128, 4, 2, 3, CONV>(p, batch, st);
     case 3: return launch_cfg<128, 128, 2, 2, 4, CONV>(p, batch, st);
-    default: return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
+    case 4: return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
+    case 5: return launch_cfg<256, 128, 2, 2, 3, CONV>(p, batch, st);
+    default: return launch_cfg<256, 256, 2, 2, 2, CONV>(p, batch, st);
     }
 }
 
