@@ -115,29 +115,34 @@ gemm_conv_kernel(const Params p) {
     int tap = 0, cc = 0;                              // conv K-tile cursor: tap (0..8), 64-channel chunk
     const int cpt = CONV ? p.Cin / BK : 1;
 
+    // conv: the per-lane byte offset of a tap is computed once per tap (when the 64-channel cursor cc wraps);
+    // the channel chunk rides in the scalar soffset.  Padding taps get an offset beyond num_records (-> zeros).
+    unsigned cvo[RA];
+    auto conv_tap_offsets = [&]() {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int iy, ix; bool ok;
+            if (p.mode == TMIX_CONV_S1)      { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
+                   ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
+            cvo[r] = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + asw[r]) * 2u : 0x80000000u;
+        }
+    };
+    if constexpr (CONV) conv_tap_offsets();
+
     auto stage = [&](int buf, int kt) {
         char* sA = smem + buf * STAGE;
         char* sW = sA + A_TILE;
-        int ky = 0, kx = 0;
-        if constexpr (CONV) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            if constexpr (CONV) {
-                int iy, ix; bool ok;
-                if (p.mode == TMIX_CONV_S1)      { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
-                else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
-                else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
-                       ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
-                const unsigned vo = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + cc * BK + asw[r]) * 2u
-                                       : 0xfffffff0u;               // beyond num_records -> zeros (padding)
-                blds16(rsA, vo, 0u, sA + (r * NW + w) * 1024);
-            } else {
-                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + (r * NW + w) * 1024);
-            }
+            if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + (r * NW + w) * 1024);
+            else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + (r * NW + w) * 1024);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + (r * NW + w) * 1024);
-        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; } }
+        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < 9) conv_tap_offsets(); } }
     };
 
     f32x16 acc[FM][FN];
@@ -392,7 +397,7 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.Wo = d->mode == TMIX_CONV_S2 ? d->W / 2 : (d->mode == TMIX_CONV_UP2 ? d->W * 2 : d->W);
     const int64_t M = (int64_t)d->B * p.Ho * p.Wo;
     if (M > 0x7fffffff / 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: too many output pixels");
-    if ((int64_t)d->B * d->H * d->W * d->Cin >= (1ll << 31) || (int64_t)d->Cout * 9 * d->Cin >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: operand extent exceeds 32-bit element offsets");
+    if ((int64_t)d->B * d->H * d->W * d->Cin >= (1ll << 30) || (int64_t)d->Cout * 9 * d->Cin >= (1ll << 30)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: operand larger than 2 GiB");
     p.A = (const bf16_t*)d->X;
     p.W = (const bf16_t*)d->Wt; p.ldw = 9 * (int64_t)d->Cin;
     p.C = (bf16_t*)d->Y; p.ldc = d->Cout;
