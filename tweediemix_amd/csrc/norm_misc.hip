@@ -71,13 +71,13 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
-                                                       bf16_t* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ ws, int64_t HW, int groups, int chunks, float eps, int silu) {
-    __shared__ float s_scale[GN_MAX_C], s_shift[GN_MAX_C];
+// combine the per-chunk partials (fp64) and fold gamma/beta: ss[b][c] = {scale, shift} with
+// y = x*scale + shift.  One tiny launch instead of redoing this in every apply workgroup.
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float2* __restrict__ ss,
+                                                          int C, int64_t HW, int groups, int chunks, float eps) {
     __shared__ float s_mean[64], s_rstd[64];
-    const int C = C1 + C2, nvec = C >> 3, cpg = C / groups;
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, cpg = C / groups;
     if (tid < groups) {
         double s = 0.0, q = 0.0;
         for (int ch = 0; ch < chunks; ++ch) {
@@ -94,27 +94,43 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
     for (int c = tid; c < C; c += 256) {
         const int g = c / cpg;
         const float sc = s_rstd[g] * gamma[c];
-        s_scale[c] = sc;
-        s_shift[c] = beta[c] - s_mean[g] * sc;
+        ss[(int64_t)b * C + c] = make_float2(sc, beta[c] - s_mean[g] * sc);
     }
+}
+
+__device__ __forceinline__ float silu_fast(float x) {     // x * sigmoid(x) with v_exp_f32 / v_rcp_f32
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
+                                                       bf16_t* __restrict__ Y, const float2* __restrict__ ss, int64_t HW, int silu) {
+    __shared__ float2 s_ss[GN_MAX_C];
+    const int C = C1 + C2, nvec = C >> 3;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) s_ss[c] = ss[(int64_t)b * C + c];
     __syncthreads();
     const int64_t total = HW * nvec;
     const int64_t per = (total + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = (int64_t)blockIdx.x * per;
     int64_t i1 = i0 + per; if (i1 > total) i1 = total;
+    int64_t p = i0 / nvec; int v = (int)(i0 - p * nvec) + tid;      // running (pixel, vector) cursor: no 64-bit division per item
+    while (v >= nvec) { v -= nvec; ++p; }
+    const int step_p = 256 / nvec, step_v = 256 - step_p * nvec;
     for (int64_t i = i0 + tid; i < i1; i += 256) {
-        const int64_t p = i / nvec; const int v = (int)(i - p * nvec);
         const int c0 = v * 8;
         const bf16_t* src = (c0 < C1) ? X1 + ((int64_t)b * HW + p) * C1 + c0 : X2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
         const uint4 raw = *(const uint4*)src;
         float f[8]; unpack8(raw, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float y = f[j] * s_scale[c0 + j] + s_shift[c0 + j];
-            if (silu) y = silu_f(y);
+            const float2 k = s_ss[c0 + j];
+            float y = f[j] * k.x + k.y;
+            if (silu) y = silu_fast(y);
             f[j] = y;
         }
         *(uint4*)(Y + ((int64_t)b * HW + p) * C + c0) = pack8(f);
+        p += step_p; v += step_v;
+        if (v >= nvec) { v -= nvec; ++p; }
     }
 }
 
@@ -322,6 +338,7 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16_t* __restrict_
 }  // namespace
 
 extern "C" int tmix_groupnorm_ws_chunks(int64_t HW) { return gn_chunks(HW); }
+extern "C" int64_t tmix_groupnorm_ws_floats(int B, int C, int groups) { return (int64_t)B * 128 * groups * 2 + (int64_t)B * C * 2; }
 
 extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                                    const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
@@ -336,8 +353,12 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     hipStream_t st = (hipStream_t)stream;
     gn_stats_kernel<<<dim3(chunks, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, ws, HW, groups, chunks);
     TMIX_LAUNCH_CHECK();
-    int64_t nb = (HW * (C / 8) + 2047) / 2048; if (nb < 1) nb = 1; if (nb > 512) nb = 512;
-    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, gamma, beta, ws, HW, groups, chunks, eps, silu);
+    // ws layout: [B*chunks*groups*2] partial sums | [B*C] float2 scale/shift
+    float2* ss = (float2*)(ws + (int64_t)B * 128 * groups * 2);
+    gn_finalize_kernel<<<B, 256, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
+    TMIX_LAUNCH_CHECK();
+    int64_t nb = (HW * (C / 8) + 2047) / 2048; if (nb < 1) nb = 1; if (nb > 1024) nb = 1024;
+    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }

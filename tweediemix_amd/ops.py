@@ -186,9 +186,8 @@ def attention(q, k, vt, H, Skv, scale, out=None):
     return out
 
 
-def groupnorm_ws(B, HW, groups, device):
-    chunks = L.load().tmix_groupnorm_ws_chunks(HW)
-    return torch.empty(B * chunks * groups * 2, device=device, dtype=torch.float32)
+def groupnorm_ws(B, C, groups, device):
+    return torch.empty(L.load().tmix_groupnorm_ws_floats(B, C, groups), device=device, dtype=torch.float32)
 
 
 def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=None, ws=None):
@@ -201,7 +200,7 @@ def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=Non
     if out is None:
         out = torch.empty(*x1.shape[:-1], C1 + C2, device=x1.device, dtype=BF16)
     if ws is None:
-        ws = groupnorm_ws(B, HW, groups, x1.device)
+        ws = groupnorm_ws(B, C1 + C2, groups, x1.device)
     L.check(lib.tmix_groupnorm_nhwc(_p(x1), C1, _p(x2), C2, _p(out), _p(gamma), _p(beta), _p(ws), B, HW, groups,
                                     float(eps), int(bool(silu)), _stream()), "tmix_groupnorm_nhwc")
     return out

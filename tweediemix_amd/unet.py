@@ -275,7 +275,7 @@ class UNetPlan:
         hid = ops.linear_small(add_in, W["add_embedding.linear_1.weight"], W["add_embedding.linear_1.bias"], act_out=True)
         self.aug = ops.linear_small(hid, W["add_embedding.linear_2.weight"], W["add_embedding.linear_2.bias"])
         torch.cuda.synchronize()
-        self._gn_ws = torch.empty(B * 128 * cfg.norm_groups * 2, device=dev, dtype=F32)
+        self._gn_ws = ops.groupnorm_ws(B, 4096, cfg.norm_groups, dev)
         self._vt = {}
         self._build()
         if autotune:
