@@ -73,28 +73,25 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
 
 // combine the per-chunk partials (fp64) and fold gamma/beta: ss[b][c] = {scale, shift} with
 // y = x*scale + shift.  One tiny launch instead of redoing this in every apply workgroup.
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float2* __restrict__ ss,
-                                                          int C, int64_t HW, int groups, int chunks, float eps) {
-    __shared__ float s_mean[64], s_rstd[64];
-    const int b = blockIdx.x, tid = threadIdx.x, cpg = C / groups;
-    if (tid < groups) {
-        double s = 0.0, q = 0.0;
-        for (int ch = 0; ch < chunks; ++ch) {
-            const float* o = ws + (((int64_t)b * chunks + ch) * groups + tid) * 2;
-            s += (double)o[0]; q += (double)o[1];
-        }
-        const double n = (double)HW * cpg;
-        const double mean = s / n;
-        double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
-        s_mean[tid] = (float)mean;
-        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float2* __restrict__ ss,
+                                                         int C, int64_t HW, int groups, int chunks, float eps) {
+    // one wave per (group, batch): lanes split the chunks, fp64 tree-combine, then write the group's channels
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, cpg = C / groups;
+    double s = 0.0, q = 0.0;
+    for (int ch = lane; ch < chunks; ch += 64) {
+        const float* o = ws + (((int64_t)b * chunks + ch) * groups + g) * 2;
+        s += (double)o[0]; q += (double)o[1];
     }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
-        const float sc = s_rstd[g] * gamma[c];
-        ss[(int64_t)b * C + c] = make_float2(sc, beta[c] - s_mean[g] * sc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const float sc = rstd * gamma[c];
+        ss[(int64_t)b * C + c] = make_float2(sc, beta[c] - meanf * sc);
     }
 }
 
@@ -355,7 +352,7 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     TMIX_LAUNCH_CHECK();
     // ws layout: [B*chunks*groups*2] partial sums | [B*C] float2 scale/shift
     float2* ss = (float2*)(ws + (int64_t)B * 128 * groups * 2);
-    gn_finalize_kernel<<<B, 256, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
+    gn_finalize_kernel<<<dim3(groups, B), 64, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
     TMIX_LAUNCH_CHECK();
     int64_t nb = (HW * (C / 8) + 2047) / 2048; if (nb < 1) nb = 1; if (nb > 1024) nb = 1024;
     gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu);
