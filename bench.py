@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (debug only; not a valid bench line)")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="independent launch chains per UNet call (rows split over HIP streams)")
+    ap.add_argument("--streams", type=int, default=2, help="independent launch chains per UNet call (rows split over HIP streams)")
     ap.add_argument("--seeds-per-gpu", type=int, default=1,
                     help="independent trajectories co-batched into every UNet launch (1 = the reference's one image per process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,8 +71,9 @@ def build_sampler(args, device, seed):
 
 
 def gemm_roofline(plan):
-    """per-launch HIP-event timing of the dominant kernel (gemm_conv_kernel<0>, the bf16 MFMA GEMM) inside
-    one eager forward: achieved = sum(algorithmic flops) / sum(launch durations)."""
+    """per-launch HIP-event timing of the dominant kernel (gemm_conv_kernel<..,0>, the bf16 MFMA GEMM) inside
+    one eager single-stream forward of the SAME launches the timed region replays:
+    achieved = sum(algorithmic flops) / sum(launch durations)."""
     import ctypes as C
     from tweediemix_amd import lib as L
     lib = L.load()
