@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     return *(uint32_t*)&v;
 }
 
-__global__ void __launch_bounds__(256, 3) attn_fwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,8 +91,12 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_kernel(const AttnParams p) {
     for (int qi = 0; qi < 2; ++qi) {
         int q = q0 + qi * 16 + fr; if (q > p.Sq - 1) q = p.Sq - 1;
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds)
-            qf[qi][ds] = *(const frag_ab*)(Qb + (int64_t)q * p.ldq + ds * 32 + fg * 8);
+        for (int ds = 0; ds < 2; ++ds) {
+            // fold softmax scale * log2(e) into Q once (one extra bf16 rounding of q, none per score)
+            const frag_ab raw = *(const frag_ab*)(Qb + (int64_t)q * p.ldq + ds * 32 + fg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qi][ds][j] = (__bf16)((float)raw[j] * p.scale_log2e);
+        }
     }
 
     // ---- staging geometry: per wave 2 rounds x (8 rows x 8 chunks) for K and for V^T
@@ -130,17 +134,22 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_kernel(const AttnParams p) {
     f32x4 o[4][2];                     // O^T accumulators: [d fragment][q fragment]
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+    float lrun[2] = {0.f, 0.f};
 
-    // one KV tile: S^T = K Q^T, online softmax in registers, O^T += V^T P^T.  MASK = tile holds keys >= Skv.
-    const float c = p.scale_log2e;                   // softmax(x*scale) = exp2(x*c - max*c) / sum
+    // one KV tile: S^T = K Q^T (already in log2 units, accumulated on top of -m so the MFMA does the subtraction),
+    // P = exp2(S^T), O^T += V^T P^T.  The running maximum m is only moved when some score exceeds it by more than
+    // THR (deferred rescale, P <= 2^THR stays well inside bf16/fp32 range), so the common path has no cross-lane
+    // traffic, no per-score subtract and no accumulator rescale.  MASK = tile holds keys >= Skv.
+    constexpr float THR = 8.0f;
+    f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // -m per query column, replicated for the MFMA C operand
+    bool first = true;
     auto tile = [&](int cur, int kv0, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
         const char* sK = smem + cur * STAGE;
         const char* sV = sK + TILE;
         f32x4 s[4][2];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { s[f][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; s[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int f = 0; f < 4; ++f) { s[f][0] = negm[0]; s[f][1] = negm[1]; }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
             const int sw = ((ds * 4 + fg) ^ (fr & 7)) << 4;
@@ -151,53 +160,58 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_kernel(const AttnParams p) {
                 s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ds], s[f][1], 0, 0, 0);
             }
         }
-        uint32_t pb[2][2][4];          // [qi][k-step] packed bf16x8 = B operand of O^T = V^T P^T
-        float alpha[2];
+        float mx[2];
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            // x = s*c first (packed multiplies): the products are canonical, so the max tree below needs no
-            // per-operand canonicalising v_max (which fmaxf on raw MFMA outputs would get).
-            f32x4 x[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) x[f] = s[f][qi] * c;
             if constexpr (MASK) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) x[f][r] = -INFINITY;
+                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) s[f][qi][r] = -INFINITY;
             }
-            float mx = fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3]));
+            // max(a,b) as med3(a,b,+inf): the target intrinsic takes raw MFMA outputs without the per-operand
+            // canonicalising v_max that fmaxf gets under IEEE mode
+            auto mx2 = [](float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); };
+            float m0 = mx2(mx2(s[0][qi][0], s[0][qi][1]), mx2(s[0][qi][2], s[0][qi][3]));
 #pragma unroll
-            for (int f = 1; f < 4; ++f) mx = fmaxf(fmaxf(mx, fmaxf(x[f][0], x[f][1])), fmaxf(x[f][2], x[f][3]));
-            mx = xor32_max(xor16_max(mx));
-            const float mnew = fmaxf(mrun[qi], mx);          // finite: tile 0 always holds a valid key
-            alpha[qi] = __builtin_amdgcn_exp2f(mrun[qi] - mnew);
-            mrun[qi] = mnew;
+            for (int f = 1; f < 4; ++f) m0 = mx2(mx2(m0, mx2(s[f][qi][0], s[f][qi][1])), mx2(s[f][qi][2], s[f][qi][3]));
+            mx[qi] = m0;
+        }
+        if (first || __any((mx[0] > THR) | (mx[1] > THR))) {
+            // move the maximum: delta = row max relative to the old m (over all 4 lane groups of the column)
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                float delta = xor32_max(xor16_max(mx[qi]));
+                if (!first) delta = fmaxf(delta, 0.f);               // never lower an established maximum
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) s[f][qi] = s[f][qi] - delta;
+#pragma unroll
+                for (int df = 0; df < 4; ++df) o[df][qi] *= alpha;
+                lrun[qi] *= alpha;
+                negm[qi] = negm[qi] - delta;
+            }
+            first = false;
+        }
+        uint32_t pb[2][2][4];          // [qi][k-step] packed bf16x8 = B operand of O^T = V^T P^T
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
             f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                x[f] = x[f] - mnew;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[f][r] = __builtin_amdgcn_exp2f(x[f][r]);
-                acc4 += x[f];
+                for (int r = 0; r < 4; ++r) s[f][qi][r] = __builtin_amdgcn_exp2f(s[f][qi][r]);
+                acc4 += s[f][qi];
             }
-            float sum = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-            sum = xor32_sum(xor16_sum(sum));
-            lrun[qi] = lrun[qi] * alpha[qi] + sum;
+            lrun[qi] += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);   // per-lane partial; lane groups are summed once at the end
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
-                pb[qi][ps][0] = pk_bf16(x[2 * ps][0], x[2 * ps][1]);
-                pb[qi][ps][1] = pk_bf16(x[2 * ps][2], x[2 * ps][3]);
-                pb[qi][ps][2] = pk_bf16(x[2 * ps + 1][0], x[2 * ps + 1][1]);
-                pb[qi][ps][3] = pk_bf16(x[2 * ps + 1][2], x[2 * ps + 1][3]);
+                pb[qi][ps][0] = pk_bf16(s[2 * ps][qi][0], s[2 * ps][qi][1]);
+                pb[qi][ps][1] = pk_bf16(s[2 * ps][qi][2], s[2 * ps][qi][3]);
+                pb[qi][ps][2] = pk_bf16(s[2 * ps + 1][qi][0], s[2 * ps + 1][qi][1]);
+                pb[qi][ps][3] = pk_bf16(s[2 * ps + 1][qi][2], s[2 * ps + 1][qi][3]);
             }
-        }
-        // rescale the running output only when some row's maximum actually moved (wave-uniform branch)
-        if (__any((alpha[0] != 1.0f) | (alpha[1] != 1.0f))) {
-#pragma unroll
-            for (int df = 0; df < 4; ++df)
-            { o[df][0] *= alpha[0]; o[df][1] *= alpha[1]; }
         }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -242,7 +256,7 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_kernel(const AttnParams p) {
     for (int qi = 0; qi < 2; ++qi) {
         const int q = q0 + qi * 16 + fr;
         if (q >= p.Sq) continue;
-        const float inv = 1.0f / lrun[qi];
+        const float inv = 1.0f / xor32_sum(xor16_sum(lrun[qi]));
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             uint2 v;
