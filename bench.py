@@ -121,6 +121,20 @@ def gemm_roofline(plan):
     return out
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH doubled per MI355X_MICROARCH.md section HBM); collected by tools/collect_profile.sh with this
+    same workload, since counters cannot be read from inside the process.  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["gemm"]["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, parts, K=3):
     """the oracle (fp32 torch-CPU restatement of the same UNet) on `cpu_rows` of the K+1 batch rows of one
     fusion step; steps/s extrapolated by (K+1)/rows (rows are independent inside the UNet)."""
@@ -211,7 +225,7 @@ def main():
             "achieved_tflops_whole_step": plan.flops / 1e12 / (dt / args.steps),
             "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<0> (tmix_gemm_bf16)", "achieved": g["tflops"],
                          "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,
-                         "traffic": None, "launches_per_step": g["launches"], "avg_launch_us": g["avg_us"],
+                         "traffic": pmc_traffic(), "launches_per_step": g["launches"], "avg_launch_us": g["avg_us"],
                          "flops_per_step": g["flops"],
                          "other_kernels": {k: {kk: v[kk] for kk in ("launches", "total_ms", "avg_us", "tflops")}
                                            for k, v in roof.items() if k != "gemm"}},

@@ -1,0 +1,35 @@
+#!/bin/bash
+# run on the GPU box: tools/collect_profile.sh <tag>
+# (1) rocprofv3 --kernel-trace --stats of the default bench command; (2) separate PMC passes for HBM traffic.
+tag=${1:-r1}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag} -- python bench.py --no-cpu-baseline > $out/bench.log 2>&1
+grep '^{"metric' $out/bench.log > $out/${tag}_bench_line.json
+for pm in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline > $out/pmc_$pm.log 2>&1
+done
+python - $out $tag <<'PY'
+import csv, sys, json, collections
+out, tag = sys.argv[1], sys.argv[2]
+res = {}
+for pm in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f"{out}/{tag}_{pm}_counter_collection.csv")):
+        if r["Counter_Name"] != pm: continue
+        n = r["Kernel_Name"]
+        key = "gemm" if "gemm_conv_kernel" in n and ", 0>" in n else "conv" if "gemm_conv_kernel" in n else "attn" if "attn_fwd" in n else None
+        if key:
+            agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
+    res[pm] = {k: {"launches": v[0], "sum_kb": v[1], "avg_kb_per_launch": v[1] / max(1, v[0])} for k, v in agg.items()}
+# guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE on gfx950 reports 1/2 of the bytes of wide coalesced reads -> x2; KB units
+summary = {}
+for k in res["FETCH_SIZE"]:
+    f = res["FETCH_SIZE"][k]["avg_kb_per_launch"]; w = res["WRITE_SIZE"].get(k, {"avg_kb_per_launch": 0})["avg_kb_per_launch"]
+    summary[k] = {"fetch_kb_raw": f, "write_kb_raw": w, "hbm_bytes_per_launch_corrected": (2 * f + w) * 1024,
+                  "launches_sampled": res["FETCH_SIZE"][k]["launches"]}
+json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+print(json.dumps(summary))
+PY
+rm -f $out/*_kernel_trace.csv $out/*counter_collection.csv $out/*agent_info.csv
+ls $out
