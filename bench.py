@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (debug only; not a valid bench line)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--trajectory", action="store_true",
+                    help="extra line: time whole 50-step trajectories (start/resampling, plain, jumping, fusion: 75 UNet calls)")
     ap.add_argument("--streams", type=int, default=2, help="independent launch chains per UNet call (rows split over HIP streams)")
     ap.add_argument("--seeds-per-gpu", type=int, default=1,
                     help="independent trajectories co-batched into every UNet launch (1 = the reference's one image per process)")
@@ -209,6 +211,24 @@ def main():
         gathered = D.gather_latents(x[:1].contiguous(), world, rank, world)
         assert gathered.shape[0] == world and torch.isfinite(gathered).all()
 
+    traj = None
+    if args.trajectory:
+        # whole sample_loop with the reference's default flags (n=50, t_cond=0.2, resampling 10, jumping 5): SURVEY 8d(ii)
+        from tweediemix_amd import masks as M
+        imgs = M.random_rectangle_masks(K, args.res, args.res, seed=7)
+        tw.mask_provider = lambda x0: (tw.masks if S > 1 else M.build_masks(imgs, tw.h, tw.w, device))
+        xT = torch.randn(S, 4, tw.h, tw.w, generator=seed_gen)
+        tw.unet_calls.clear()
+        tw.run_fusion(xT.clone())                       # builds/captures the start and plain plans too
+        torch.cuda.synchronize()
+        n_calls = len(tw.unet_calls)
+        t1 = time.perf_counter()
+        out = tw.run_fusion(xT.clone())
+        torch.cuda.synchronize()
+        dtt = time.perf_counter() - t1
+        assert torch.isfinite(out).all()
+        traj = {"trajectory_steps_per_s": 50 * S / dtt, "seconds_per_image": dtt / S, "unet_calls_per_image": n_calls,
+                "calls_B4": sum(1 for c in tw.unet_calls[n_calls:] if c[1] == K + 1), "calls_B2": sum(1 for c in tw.unet_calls[n_calls:] if c[1] == 2)}
     if rank == 0:
         roof = gemm_roofline(plan)
         g = roof["gemm"]
@@ -230,6 +250,8 @@ def main():
                          "other_kernels": {k: {kk: v[kk] for kk in ("launches", "total_ms", "avg_us", "tflops")}
                                            for k, v in roof.items() if k != "gemm"}},
         }
+        if traj is not None:
+            line["trajectory"] = traj
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, parts)
         print(json.dumps(line), flush=True)
