@@ -104,7 +104,7 @@ typedef struct {
 } tmix_conv_desc;
 int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
 
-/* conv_in: fp32 NCHW latent [B,Cin<=8,H,W] -> bf16 NHWC [B,H,W,Cout]; weights fp32 OHWI. */
+/* conv_in: fp32 NCHW latent [B,4,H,W] -> bf16 NHWC [B,H,W,Cout] (Cout % 32 == 0); weights fp32 OHWI. */
 int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
                  int B, int Cin, int H, int W, int Cout, void* stream);
 /* conv_out: bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,Cout<=8,H,W]; weights bf16 OHWI. */

@@ -253,19 +253,25 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------ conv_in (fp32 VALU)
-// thread = one output pixel x 8 consecutive output channels; weights fp32 OHWI [Cout][3][3][Cin]
+// workgroup = 64 consecutive output pixels x all Cout; lane = pixel (its 3x3xCIN patch lives in registers), wave q
+// owns a quarter of the output channels; the fp32 OHWI weights are staged once per workgroup in LDS and read as
+// wave-uniform broadcasts.  fp32 math (the latent is not rounded to bf16 before the first convolution).
 template <int CIN>
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                       int B, int H, int W, int Cout) {
-    const int ncg = Cout >> 3;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];        // [Cout][9*CIN]
+    constexpr int KK = 9 * CIN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < Cout * KK / 4; i += 256) ((float4*)s_w)[i] = ((const float4*)w)[i];
     const int64_t npix = (int64_t)B * H * W;
-    if (gid >= npix * ncg) return;
-    const int64_t pix = gid / ncg; const int cg = (int)(gid - pix * ncg);
+    int64_t pix = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = pix < npix;
+    if (!live) pix = npix - 1;
     const int b = (int)(pix / ((int64_t)H * W)); const int rem = (int)(pix - (int64_t)b * H * W);
     const int oy = rem / W, ox = rem - oy * W;
-    float patch[9 * CIN];
+    float patch[KK];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -276,17 +282,20 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
             for (int ci = 0; ci < CIN; ++ci)
                 patch[(ky * 3 + kx) * CIN + ci] = ok ? x[(((int64_t)b * CIN + ci) * H + iy) * W + ix] : 0.f;
         }
-    float o[8];
+    __syncthreads();
+    const int cpq = Cout / 4;                      // output channels per wave (multiple of 8)
+    for (int c0 = q * cpq; c0 < (q + 1) * cpq; c0 += 8) {
+        float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int co = cg * 8 + j;
-        float a = bias ? bias[co] : 0.f;
-        const float* wr = w + (int64_t)co * 9 * CIN;
+        for (int j = 0; j < 8; ++j) {
+            const float* wr = s_w + (c0 + j) * KK;
+            float a = bias ? bias[c0 + j] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 9 * CIN; ++k) a += patch[k] * wr[k];
-        o[j] = a;
+            for (int k = 0; k < KK; ++k) a += patch[k] * wr[k];
+            o[j] = a;
+        }
+        if (live) *(uint4*)(y + pix * Cout + c0) = pack8(o);
     }
-    *(uint4*)(y + pix * Cout + cg * 8) = pack8(o);
 }
 
 // ------------------------------------------------------------------------------ conv_out (MFMA)
@@ -405,14 +414,17 @@ extern "C" int tmix_linear_small(const float* in, const void* W, const float* bi
 extern "C" int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
                             int B, int Cin, int H, int W, int Cout, void* stream) {
     if (!x_nchw || !w_ohwi || !y_nhwc) TMIX_FAIL(TMIX_EINVAL, "conv_in: null pointer");
-    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 8)) TMIX_FAIL(TMIX_ESHAPE, "conv_in: bad shape");
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv_in: bad shape");
     if (!aligned16(y_nhwc)) TMIX_FAIL(TMIX_EALIGN, "conv_in: output must be 16-byte aligned");
-    const int64_t n = (int64_t)B * H * W * (Cout / 8);
-    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (Cout % 32) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d must be a multiple of 32", Cout);
+    if (Cin != 4) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (only the 4-channel latent is supported)", Cin);
+    if (!aligned16(w_ohwi)) TMIX_FAIL(TMIX_EALIGN, "conv_in: weights must be 16-byte aligned");
+    const int64_t npix = (int64_t)B * H * W;
+    const unsigned nb = (unsigned)((npix + 63) / 64);
+    const int smem = Cout * 36 * 4;
+    if (smem > 64 * 1024) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d too large for the LDS weight stage", Cout);
     hipStream_t st = (hipStream_t)stream;
-    if (Cin == 4)      conv_in_kernel<4><<<nb, 256, 0, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout);
-    else if (Cin == 8) conv_in_kernel<8><<<nb, 256, 0, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout);
-    else TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (4 or 8 supported)", Cin);
+    conv_in_kernel<4><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
