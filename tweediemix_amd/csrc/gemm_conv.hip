@@ -196,10 +196,30 @@ gemm_conv_kernel(const Params p) {
     if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
+    const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
+    const bool plain_epi = !trans && p.epilogue == TMIX_EPI_NONE;
+    constexpr bool PREF = FM * FN <= 4;               // large wave tiles have no registers to spare for it
+    uint2 rres[PREF ? FM : 1][PREF ? FN : 1][4];
+    auto prefetch_residual = [&]() {
+        if constexpr (PREF)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            int m = m0 + wr * TM + i * 32 + l31; if (m > p.M - 1) m = p.M - 1;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int n = n0 + wc * TN + j * 32 + g * 8 + lhi * 4; if (n > p.N - 4) n = p.N - 4;
+                    rres[i][j][g] = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
+                }
+        }
+    };
     int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + NS - 1 < nk;
         if (more) stage(nxt, kt + NS - 1);
+        if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
         compute(cur);
         if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -242,7 +262,6 @@ gemm_conv_kernel(const Params p) {
     }
 
     bf16_t* Cb = p.C + (int64_t)bz * p.strideC;
-    const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
     if (p.epilogue == TMIX_EPI_GEGLU) {
         // weight rows are interleaved in 16-row groups [value_j | gate_j]: within a 32-row fragment, accumulator
         // register groups g=0,1 (rows 0-15) are the value half and g=2,3 (rows 16-31) the gate half.
@@ -288,7 +307,9 @@ gemm_conv_kernel(const Params p) {
                 if (bias) { const float4 b4 = *(const float4*)(bias + n); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
                 if (rg)   { const float4 b4 = *(const float4*)(rg + n);   o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
                 if (Rb) {
-                    const uint2 rv = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
+                    uint2 rv;
+                    if constexpr (PREF) rv = rres[i][j][g];
+                    else rv = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
                     o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
                     o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
                 }
