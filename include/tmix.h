@@ -69,7 +69,8 @@ int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, cons
 enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1 };
 /* workgroup tilings of the MFMA mainloop (BM x BN, waves, LDS ring depth); AUTO = built-in heuristic */
 enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, TMIX_TILE_128x128_S4 = 3,
-       TMIX_TILE_256x256_S2 = 4, TMIX_TILE_256x128_W4 = 5, TMIX_TILE_256x256_W4 = 6, TMIX_TILE_COUNT = 6 };
+       TMIX_TILE_256x256_S2 = 4, TMIX_TILE_256x128_W4 = 5, TMIX_TILE_256x256_W4 = 6, TMIX_TILE_128x160_S2 = 7,
+       TMIX_TILE_COUNT = 7 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

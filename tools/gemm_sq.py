@@ -14,7 +14,7 @@ for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (4096, 1280, 1280), (4
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
     out = torch.empty(M, N, device="cuda", dtype=BF)
     res = []
-    for cfg in (1, 2, 3, 4, 5, 6):
+    for cfg in (1, 2, 4, 7):
         d = ops.make_gemm_desc(a, w, out, tile_cfg=cfg)
         st = torch.cuda.current_stream().cuda_stream
         us = timeit(lambda: lib.tmix_gemm_bf16(C.byref(d), st))

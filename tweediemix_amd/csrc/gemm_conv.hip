@@ -326,7 +326,9 @@ struct TileCfg { int bm, bn; };
 // 5 = 256x128 (4 waves of 128x64, 3 stages, 1 WG/CU), 6 = 256x256 (4 waves of 128x128, 2 stages, 1 WG/CU):
 // one wave per SIMD with a large register tile -- on this chip instructions of co-resident waves do not overlap on a
 // SIMD, so MFMA utilisation is set by MFMAs per non-MFMA instruction, i.e. by the wave tile.
-constexpr int NUM_CFG = 6;
+// 7 = 128x160 (4 waves of 32x160, 2 stages): N = 1280 / 640 split into 160-wide tiles gives exactly 256 / 512 tiles
+// for this path's M = 4096 / 16384 GEMMs, i.e. whole rounds on 256 CUs instead of 1.25 / 2.5.
+constexpr int NUM_CFG = 7;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -357,14 +359,15 @@ int pick_cfg(const Params& p, int batch) {
 template <int CONV>
 int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
-    if ((cfg == 4 || cfg == 5) && p.n_trans_begin >= 0) cfg = 2;   // transposed stores need square wave tiles
+    if ((cfg == 4 || cfg == 5 || cfg == 7) && p.n_trans_begin >= 0) cfg = 2;   // transposed stores need square wave tiles
     switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 2, CONV>(p, batch, st);
     case 2: return launch_cfg<256, 128, 4, 2, 3, CONV>(p, batch, st);
     case 3: return launch_cfg<128, 128, 2, 2, 4, CONV>(p, batch, st);
     case 4: return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
     case 5: return launch_cfg<256, 128, 2, 2, 3, CONV>(p, batch, st);
-    default: return launch_cfg<256, 256, 2, 2, 2, CONV>(p, batch, st);
+    case 6: return launch_cfg<256, 256, 2, 2, 2, CONV>(p, batch, st);
+    default: return launch_cfg<128, 160, 4, 1, 2, CONV>(p, batch, st);
     }
 }
 

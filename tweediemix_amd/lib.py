@@ -15,7 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
 CONV_S1, CONV_S2, CONV_UP2 = 0, 1, 2
-TILE_AUTO, TILE_COUNT = 0, 6
+TILE_AUTO, TILE_COUNT = 0, 7
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

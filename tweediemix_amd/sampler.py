@@ -79,6 +79,7 @@ class Tweediemix:
         self.n_seeds = int(n_seeds)
         # n_streams > 1 splits the rows of every UNet call into that many independent launch chains (PlanGroup)
         self.n_streams = int(n_streams)
+        self.min_rows_per_stream = 1
         self.text_embeds = text_embeds
         self.text_embeds_single = text_embeds_single
         self.mask_provider = mask_provider
@@ -126,7 +127,7 @@ class Tweediemix:
         if S > 1:                                     # seed-major rows: b = seed * rows_per_seed + row
             ehs, pooled, wsel = ehs.repeat(S, 1, 1), pooled.repeat(S, 1), list(wsel) * S
         B = ehs.shape[0]
-        if self.n_streams > 1 and B % self.n_streams == 0:
+        if self.n_streams > 1 and B % self.n_streams == 0 and B // self.n_streams >= self.min_rows_per_stream:
             return PlanGroup(self.W, self.h, self.w, ehs, wsel, pooled, self.add_time_ids.repeat(B, 1), routed,
                              self.n_streams)
         kv = KVCache(self.W, ehs, wsel)
