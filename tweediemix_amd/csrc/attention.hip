@@ -134,7 +134,6 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     f32x4 o[4][2];                     // O^T accumulators: [d fragment][q fragment]
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    float lrun[2] = {0.f, 0.f};
 
     // one KV tile: S^T = K Q^T (already in log2 units, accumulated on top of -m so the MFMA does the subtraction),
     // P = exp2(S^T), O^T += V^T P^T.  The running maximum m is only moved when some score exceeds it by more than
@@ -142,54 +141,64 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     // traffic, no per-score subtract and no accumulator rescale.  MASK = tile holds keys >= Skv.
     constexpr float THR = 8.0f;
     f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // -m per query column, replicated for the MFMA C operand
+    f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // softmax denominators, accumulated BY THE MATRIX CORE
+    frag_ab ones;                                                     // A operand of all 1.0: D[i][q] = sum_k P^T[k][q]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     bool first = true;
     auto tile = [&](int cur, int kv0, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
         const char* sK = smem + cur * STAGE;
         const char* sV = sK + TILE;
         f32x4 s[4][2];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) { s[f][0] = negm[0]; s[f][1] = negm[1]; }
-#pragma unroll
-        for (int ds = 0; ds < 2; ++ds) {
-            const int sw = ((ds * 4 + fg) ^ (fr & 7)) << 4;
+        {
+            const int sw0 = ((0 * 4 + fg) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fg) ^ (fr & 7)) << 4;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                const frag_ab kf = *(const frag_ab*)(sK + (f * 16 + fr) * 128 + sw);
-                s[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ds], s[f][0], 0, 0, 0);
-                s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ds], s[f][1], 0, 0, 0);
+                const frag_ab k0 = *(const frag_ab*)(sK + (f * 16 + fr) * 128 + sw0);
+                s[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0][0], negm[0], 0, 0, 0);
+                s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[1][0], negm[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const frag_ab k1 = *(const frag_ab*)(sK + (f * 16 + fr) * 128 + sw1);
+                s[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[0][1], s[f][0], 0, 0, 0);
+                s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1][1], s[f][1], 0, 0, 0);
             }
         }
-        float mx[2];
+        if constexpr (MASK) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            if constexpr (MASK) {
+            for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) s[f][qi][r] = -INFINITY;
-            }
-            // max(a,b) as med3(a,b,+inf): the target intrinsic takes raw MFMA outputs without the per-operand
-            // canonicalising v_max that fmaxf gets under IEEE mode
-            auto mx2 = [](float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); };
-            float m0 = mx2(mx2(s[0][qi][0], s[0][qi][1]), mx2(s[0][qi][2], s[0][qi][3]));
-#pragma unroll
-            for (int f = 1; f < 4; ++f) m0 = mx2(mx2(m0, mx2(s[f][qi][0], s[f][qi][1])), mx2(s[f][qi][2], s[f][qi][3]));
-            mx[qi] = m0;
         }
-        if (first || __any((mx[0] > THR) | (mx[1] > THR))) {
+        // threshold test on the raw bit patterns: for "is any score > THR (> 0)" signed-integer order equals float
+        // order (negative floats are negative ints), and integer max needs no IEEE canonicalisation of MFMA outputs.
+        int im = 0x80000000;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                im = max(max(im, max(__float_as_int(s[f][qi][0]), __float_as_int(s[f][qi][1]))),
+                         max(__float_as_int(s[f][qi][2]), __float_as_int(s[f][qi][3])));
+        if (first || __any(im > __float_as_int(THR))) {
             // move the maximum: delta = row max relative to the old m (over all 4 lane groups of the column)
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
-                float delta = xor32_max(xor16_max(mx[qi]));
+                float m0 = fmaxf(fmaxf(s[0][qi][0], s[0][qi][1]), fmaxf(s[0][qi][2], s[0][qi][3]));
+#pragma unroll
+                for (int f = 1; f < 4; ++f) m0 = fmaxf(fmaxf(m0, fmaxf(s[f][qi][0], s[f][qi][1])), fmaxf(s[f][qi][2], s[f][qi][3]));
+                float delta = xor32_max(xor16_max(m0));
                 if (!first) delta = fmaxf(delta, 0.f);               // never lower an established maximum
                 const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                 for (int f = 0; f < 4; ++f) s[f][qi] = s[f][qi] - delta;
 #pragma unroll
                 for (int df = 0; df < 4; ++df) o[df][qi] *= alpha;
-                lrun[qi] *= alpha;
+                lacc[qi] *= alpha;
                 negm[qi] = negm[qi] - delta;
             }
             first = false;
@@ -197,14 +206,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
         uint32_t pb[2][2][4];          // [qi][k-step] packed bf16x8 = B operand of O^T = V^T P^T
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[f][qi][r] = __builtin_amdgcn_exp2f(s[f][qi][r]);
-                acc4 += s[f][qi];
-            }
-            lrun[qi] += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);   // per-lane partial; lane groups are summed once at the end
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 pb[qi][ps][0] = pk_bf16(s[2 * ps][qi][0], s[2 * ps][qi][1]);
@@ -219,6 +224,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
             frag_ab p0, p1;
             __builtin_memcpy(&p0, pb[0][ps], 16);
             __builtin_memcpy(&p1, pb[1][ps], 16);
+            // row sums of the bf16-rounded P (exactly what multiplies V): one MFMA per (k-step, query fragment)
+            lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, lacc[0], 0, 0, 0);
+            lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, lacc[1], 0, 0, 0);
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
                 const frag_ab vf = *(const frag_ab*)(sV + (df * 16 + fr) * 128 + sw);
@@ -256,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     for (int qi = 0; qi < 2; ++qi) {
         const int q = q0 + qi * 16 + fr;
         if (q >= p.Sq) continue;
-        const float inv = 1.0f / xor32_sum(xor16_sum(lrun[qi]));
+        const float inv = 1.0f / lacc[qi][0];        // every row of the ones-MFMA result holds the full key sum
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             uint2 v;
