@@ -170,11 +170,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    if os.environ.get("TMIX_SINGLE_GPU_DIST_TEST"):     # debug only: all ranks share GPU 0 over gloo (control-flow test)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if os.environ.get("TMIX_SINGLE_GPU_DIST_TEST"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     tw, parts = build_sampler(args, device, seed=rank)       # each rank owns its own seeds (weak scaling)
     K = tw.concept_num

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's `python fusion_generation/fusion_sampling.py ...` (Custom-Diffusion weights).
+
+Accepts the reference's argv unchanged (flags of fusion_sampling.py:534-585; `+`-separated lists, background
+concept last) and runs the same Tweedie-mix loop on the MI355X-native sampler.  What the reference does around
+the loop but this repository does not build (SURVEY 8f "next" rows) is replaced by explicit inputs:
+
+  --unet_path            diffusers-format SDXL UNet weights (.safetensors / torch state dict); the concept
+                         checkpoints of --personal_checkpoint (delta-*.bin, key 'unet') load unchanged
+  --text_embeds_path     torch file {'text_embeds': (E[K+2,77,2048], P[K+2,1280]),
+                                     'text_embeds_single': (E[K,77,2048], P[K,1280])}  (CLIP encoders are out of scope)
+  --mask_paths           '+'-separated 8-bit masks for the foreground concepts (what run_expand.py would write
+                         as '<concept>.jpg'); --random_masks draws seeded rectangles instead
+  --synthetic            random-init weights / embeddings of the SDXL shapes (no checkpoints exist offline)
+
+Output: {output_path_all}/{prompt_orig}_{seed}.latent.pt (the VAE decode to PNG is a "next" row).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LORA = False
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # --- the reference's flags, same names / defaults (fusion_sampling.py:534-585)
+    p.add_argument('--seed', type=int, default=182)
+    p.add_argument('--device', type=str, default='cuda')
+    p.add_argument('--output_path', type=str, default='results')
+    p.add_argument('--output_path_all', type=str, default='results_all')
+    p.add_argument('--negative_prompt', type=str, default='')
+    p.add_argument('--sd_version', type=str, default='xl', choices=['1.4', '1.5', '2.0', '2.1', 'xl'])
+    p.add_argument('--t_cond', type=float, default=0.4)
+    p.add_argument('--guidance_scale', type=float, default=9.0)
+    p.add_argument('--n_timesteps', type=int, default=50)
+    p.add_argument('--prompt', type=str, default='')
+    p.add_argument('--prompt_orig', type=str, default='')
+    p.add_argument('--seg_concepts', type=str, default='')
+    p.add_argument('--personal_checkpoint', type=str, default='')
+    p.add_argument('--concepts', type=str, default='')
+    p.add_argument('--modifier_token', type=str, default='')
+    p.add_argument('--resampling_steps', type=int, default=10)
+    p.add_argument('--jumping_steps', type=int, default=5)
+    p.add_argument('--seg_gpu', type=int, default=1)
+    p.add_argument('--crops_coords_top_left_h', type=int, default=0)
+    p.add_argument('--crops_coords_top_left_w', type=int, default=0)
+    p.add_argument('--resolution_h', type=int, default=1024)
+    p.add_argument('--resolution_w', type=int, default=1024)
+    if LORA:
+        p.add_argument('--t_stop', type=float, default=0.9)          # fusion_sampling_lora.py:547
+    # --- additive flags
+    p.add_argument('--synthetic', action='store_true')
+    p.add_argument('--unet_path', type=str, default='')
+    p.add_argument('--text_embeds_path', type=str, default='')
+    p.add_argument('--mask_paths', type=str, default='')
+    p.add_argument('--random_masks', action='store_true')
+    p.add_argument('--num_seeds', type=int, default=1, help='co-batched trajectories (seeds seed..seed+n-1)')
+    p.add_argument('--streams', type=int, default=2)
+    p.add_argument('--no_graphs', action='store_true')
+    p.add_argument('--tiny', action='store_true', help='tiny UNet config (smoke tests)')
+    return p
+
+
+def load_state_dict(path):
+    if path.endswith('.safetensors'):
+        from safetensors.torch import load_file
+        return load_file(path)
+    sd = torch.load(path, map_location='cpu')
+    return sd.get('state_dict', sd)
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
+    if opt.sd_version != 'xl':
+        print(f"note: --sd_version {opt.sd_version}: like the reference (fusion_sampling.py:119) only the SDXL pipeline exists")
+    concepts = [c for c in opt.concepts.split('+') if c] or ['a', 'b', 'background']
+    K = len(concepts)                                    # concept_num, background last (fusion_sampling.py:143-148)
+    cfg = U.TINY if opt.tiny else U.SDXL
+    kind = 'lora' if LORA else 'custom'
+    S.seed_everything(opt.seed)
+    if opt.synthetic:
+        sd = Wt.synthetic_state_dict(cfg, seed=1234, device=opt.device, dtype=torch.bfloat16)
+        con = Wt.synthetic_concepts(cfg, kind, K, device=opt.device)
+        g = torch.Generator().manual_seed(42)
+        te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g), torch.randn(K + 2, cfg.pooled_dim, generator=g))
+        ts = (torch.randn(K, 77, cfg.cross_dim, generator=g), torch.randn(K, cfg.pooled_dim, generator=g))
+    else:
+        if not (opt.unet_path and opt.text_embeds_path and opt.personal_checkpoint):
+            sys.exit("need --unet_path, --text_embeds_path and --personal_checkpoint (or --synthetic); "
+                     "HF hub download / CLIP text encoders are outside this repository's scope")
+        sd = load_state_dict(opt.unet_path)
+        con = [torch.load(p, map_location='cpu')['unet'] for p in opt.personal_checkpoint.split('+')]   # :156-157
+        emb = torch.load(opt.text_embeds_path, map_location='cpu')
+        te, ts = emb['text_embeds'], emb['text_embeds_single']
+    W = U.UNetWeights(cfg, sd, opt.device, (kind, con))
+    h, w = opt.resolution_h // 8, opt.resolution_w // 8
+    if opt.mask_paths:
+        fg = opt.mask_paths.split('+')
+    elif opt.random_masks or opt.synthetic:
+        fg = M.random_rectangle_masks(K, opt.resolution_h, opt.resolution_w, seed=opt.seed)
+    else:   # the reference's file contract: the side-car wrote '<seg_concept>.jpg' under output_path (:461-466)
+        fg = [os.path.join(opt.output_path, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
+    tw = S.Tweediemix(opt, W, te, ts, lambda x0: M.build_masks(fg, h, w, opt.device), concept_num=K, lora=LORA,
+                      use_graphs=not opt.no_graphs, n_seeds=opt.num_seeds, n_streams=opt.streams)
+    x = torch.randn(opt.num_seeds, 4, h, w)             # CPU draw after seed_everything, like :488
+    lat = tw.run_fusion(x)
+    os.makedirs(opt.output_path_all, exist_ok=True)
+    prompt_orig = opt.prompt_orig.split('+')[0] or 'sample'
+    for i in range(opt.num_seeds):
+        out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.latent.pt'
+        torch.save(lat[i:i + 1].cpu(), out)
+        print('saved', out)
+    return lat
+
+
+if __name__ == '__main__':
+    main()

@@ -201,3 +201,26 @@ def test_two_seeds_co_batched_equal_independent_runs():
         for i in range(2):
             torch.testing.assert_close(both[i:i + 1], singles[i], rtol=1e-3, atol=1e-3)
         assert tw2.plan("fusion").B == 8 and [c[1] for c in tw2.unet_calls][:1] == [4]
+
+
+def test_cli_drop_in_flags(tmp_path):
+    """the drop-in scripts accept the reference's argv (sample_catdog.sh / sample_panda.sh flag sets)."""
+    need_gpu()
+    import importlib.util
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fs_cli", _os.path.join(root, "fusion_generation", "fusion_sampling.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
+    argv = ["--synthetic", "--tiny", "--seed", "5", "--prompt", "a cat+a dog+a mountain", "--prompt_orig", "cat and dog",
+            "--concepts", "cat+dog+mountain", "--modifier_token", "<new1>+<new2>+<new3>", "--seg_concepts", "a cat+a dog",
+            "--guidance_scale", "0.8", "--n_timesteps", "10", "--t_cond", "0.2", "--resampling_steps", "1",
+            "--jumping_steps", "1", "--resolution_h", "128", "--resolution_w", "128",
+            "--output_path", str(tmp_path), "--output_path_all", str(tmp_path / "all")]
+    lat = fs.main(argv)
+    assert lat.shape == (1, 4, 16, 16) and torch.isfinite(lat).all()
+    assert (tmp_path / "all" / "cat and dog_5.latent.pt").exists()
+    fs.LORA = True
+    lat2 = fs.main(argv + ["--t_stop", "0.8"])
+    fs.LORA = False
+    assert torch.isfinite(lat2).all()

@@ -285,6 +285,13 @@ class UNetPlan:
         """pick the fastest workgroup tiling (TMIX_TILE_*) per distinct GEMM / conv shape by timing the
         candidates on the device (the shapes of this path are small and awkward -- M=4096, N=1280 -- so
         tile quantisation over 256 CUs, not peak MFMA rate, decides).  Descriptors are patched in place."""
+        import os
+        force = int(os.environ.get("TMIX_FORCE_TILE", "0"))          # debugging / sensitivity studies
+        if force:
+            for kind in ("gemm", "conv"):
+                for d, _fl in self.launches[kind]:
+                    d.tile_cfg = force
+            return
         st = torch.cuda.current_stream().cuda_stream
         for kind, fn in (("gemm", self.lib.tmix_gemm_bf16), ("conv", self.lib.tmix_conv3x3_nhwc)):
             for d, _fl in self.launches[kind]:
