@@ -66,7 +66,7 @@ int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, cons
  * strideW != 0 selects one weight set per batch row).
  * Requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned pointers.
  */
-enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1 };
+enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1, TMIX_EPI_F32OUT = 2 /* C is fp32 [M][ldc] (attention scores of the VAE) */ };
 /* workgroup tilings of the MFMA mainloop (BM x BN, waves, LDS ring depth); AUTO = built-in heuristic */
 enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, TMIX_TILE_128x128_S4 = 3,
        TMIX_TILE_256x256_S2 = 4, TMIX_TILE_256x128_W4 = 5, TMIX_TILE_256x256_W4 = 6, TMIX_TILE_128x160_S2 = 7,
@@ -108,6 +108,10 @@ int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
 /* conv_in: fp32 NCHW latent [B,4,H,W] -> bf16 NHWC [B,H,W,Cout] (Cout % 32 == 0); weights fp32 OHWI. */
 int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
                  int B, int Cin, int H, int W, int Cout, void* stream);
+/* same with a per-pixel 4x4 linear map applied to the latent first (host pointers: pre_w[16] row-major, pre_b[4]):
+ * the VAE's 1/scaling_factor and post_quant_conv (AutoencoderKL.decode), exact at the zero-padded border. */
+int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
+                     int B, int Cin, int H, int W, int Cout, const float* pre_w, const float* pre_b, void* stream);
 /* conv_out: bf16 NHWC [B,H,W,Cin] -> fp32 NCHW [B,Cout<=8,H,W]; weights bf16 OHWI. */
 int tmix_conv_out(const void* x_nhwc, const void* w_ohwi, const float* bias, float* y_nchw,
                   int B, int Cin, int H, int W, int Cout, void* stream);
@@ -141,6 +145,11 @@ int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta
 int tmix_concat_channels(const void* X1, int C1, const void* X2, int C2, void* Y, int64_t rows, void* stream);
 /* sinusoidal embedding (flip_sin_to_cos=True, shift 0): out[i] = [cos(v_i f_j) | sin(v_i f_j)], j<dim/2 */
 int tmix_timestep_embedding(const float* values, float* out, int count, int dim, void* stream);
+/* row softmax: P[r][c] = softmax_c(scale * S[r][c]), S fp32 [rows][ld_s] -> P bf16 [rows][ld_p] (VAE mid-block attention,
+ * single head of dim 512: scores come from tmix_gemm_bf16 with TMIX_EPI_F32OUT). */
+int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale, void* stream);
+/* y = clamp(x*scale + shift, lo, hi) on fp32 (image post-processing (img/2+0.5).clamp(0,1), fusion_sampling.py:302) */
+int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
 /* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 16.
  * act: 0 none, 1 SiLU.  add (nullable): fp32 [M,N] added before act_out. */
 int tmix_linear_small(const float* in, const void* W, const float* bias, const float* add, float* out,

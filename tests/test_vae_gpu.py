@@ -1,0 +1,49 @@
+"""GPU: the VAE decoder plan ("next" row: final decode / preview of fusion_sampling.py:297-303, 496-528) against the
+fp32 torch oracle of the same architecture and weights.  Tolerance: image values in [0,1]; max-abs error <= 2e-2,
+rel L2 <= 2e-2 (bf16 activations vs fp32)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,h,w,inv", [(1, 16, 16, 1 / 0.13025), (2, 8, 16, 1 / 0.18215)])
+def test_vae_decoder_matches_oracle(B, h, w, inv):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import vae_oracle as VO
+    from tweediemix_amd import vae as V
+    assert V.param_shapes(V.TINY) == VO.param_shapes(VO.TINY) and V.param_shapes(V.FULL) == VO.param_shapes(VO.FULL)
+    sd = V.synthetic_state_dict(V.TINY, nontrivial=True)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(B, 4, h, w, generator=g) * 0.13025 * 3
+    ref = VO.VAEDecoderOracle(VO.TINY, sd).decode(z, inv)
+    plan = V.VAEDecoderPlan(V.TINY, sd, B, h, w, inv)
+    img = plan(z.cuda()).cpu()
+    torch.cuda.synchronize()
+    assert img.shape == ref.shape == (B, 3, 8 * h, 8 * w) and torch.isfinite(img).all()
+    err = (img - ref).abs().max().item()
+    rel = ((img - ref).norm() / ref.norm()).item()
+    print(f"vae decode B={B} {h}x{w}: max abs {err:.4g} rel L2 {rel:.4g} (image std {ref.std().item():.3f})")
+    assert err <= 2e-2 and rel <= 2e-2
+    assert ref.std().item() > 0.05          # the test image is not a constant (clamp did not flatten it)
+
+
+def test_softmax_rows_and_f32_gemm():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes as C
+    from tweediemix_amd import lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(2, 192, 128, generator=g).to(torch.bfloat16).cuda()
+    k = torch.randn(2, 256, 128, generator=g).to(torch.bfloat16).cuda()
+    s = torch.empty(2, 192, 256, device="cuda", dtype=torch.float32)
+    d = ops.make_gemm_desc(q, k, None)
+    d.C, d.ldc, d.strideC, d.epilogue = s.data_ptr(), 256, 192 * 256, L.EPI_F32OUT
+    L.check(lib.tmix_gemm_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream))
+    ref = torch.einsum("bmk,bnk->bmn", q.float(), k.float())
+    torch.testing.assert_close(s, ref, rtol=1e-4, atol=1e-3)
+    p = torch.empty(2, 192, 256, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.tmix_softmax_rows(s.data_ptr(), 256, p.data_ptr(), 256, 2 * 192, 256, 0.0884, torch.cuda.current_stream().cuda_stream))
+    torch.testing.assert_close(p.float(), torch.softmax(ref * 0.0884, -1), rtol=2 ** -7, atol=2e-3)

@@ -198,7 +198,7 @@ gemm_conv_kernel(const Params p) {
     asm volatile("" ::: "memory");
     // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
     const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
-    const bool plain_epi = !trans && p.epilogue == TMIX_EPI_NONE;
+    const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU;
     constexpr bool PREF = FM * FN <= 4;               // large wave tiles have no registers to spare for it
     uint2 rres[PREF ? FM : 1][PREF ? FN : 1][4];
     auto prefetch_residual = [&]() {
@@ -313,8 +313,12 @@ gemm_conv_kernel(const Params p) {
                     o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
                     o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
                 }
-                uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
-                *(uint2*)(Cb + (int64_t)m * p.ldc + n) = v;
+                if (p.epilogue == TMIX_EPI_F32OUT) {
+                    *(float4*)((float*)p.C + (int64_t)bz * p.strideC + (int64_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                    *(uint2*)(Cb + (int64_t)m * p.ldc + n) = v;
+                }
             }
     }
 }
@@ -388,7 +392,8 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     if (d->bias && (((uintptr_t)d->bias) & 15)) TMIX_FAIL(TMIX_EALIGN, "gemm: bias must be 16-byte aligned");
     if (d->rowgroup_bias && (d->rows_per_group <= 0 || (((uintptr_t)d->rowgroup_bias) & 15))) TMIX_FAIL(TMIX_EINVAL, "gemm: rowgroup_bias needs rows_per_group > 0 and 16-byte alignment");
     if (d->epilogue == TMIX_EPI_GEGLU && ((d->N % 32) || has_trans || d->residual || d->rowgroup_bias)) TMIX_FAIL(TMIX_EINVAL, "gemm: GEGLU needs N %% 32 == 0 and no residual/transposed region");
-    if (d->epilogue != TMIX_EPI_NONE && d->epilogue != TMIX_EPI_GEGLU) TMIX_FAIL(TMIX_EINVAL, "gemm: bad epilogue %d", d->epilogue);
+    if (d->epilogue != TMIX_EPI_NONE && d->epilogue != TMIX_EPI_GEGLU && d->epilogue != TMIX_EPI_F32OUT) TMIX_FAIL(TMIX_EINVAL, "gemm: bad epilogue %d", d->epilogue);
+    if (d->epilogue == TMIX_EPI_F32OUT && (has_trans || (((uintptr_t)d->C) & 15))) TMIX_FAIL(TMIX_EINVAL, "gemm: fp32 output needs a 16-byte aligned C and no transposed region");
     if ((int64_t)d->M * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldw >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm: operand extent exceeds 32-bit element offsets");
     Params p = {};
     p.A = (const bf16_t*)d->A; p.lda = d->lda; p.strideA = d->strideA;

@@ -183,6 +183,51 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------ row softmax (fp32 -> bf16)
+// one workgroup per row; the row (<= 64K columns) is streamed three times from L2/HBM (max, sum, write)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ S, int64_t ld_s, bf16_t* __restrict__ P,
+                                                           int64_t ld_p, int cols, float scale_log2e) {
+    __shared__ float red[4];
+    const float* row = S + (int64_t)blockIdx.x * ld_s;
+    bf16_t* out = P + (int64_t)blockIdx.x * ld_p;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mx = -INFINITY;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const float4 v = *(const float4*)(row + c);
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const float4 v = *(const float4*)(row + c);
+        sum += exp2f(v.x * scale_log2e - mx) + exp2f(v.y * scale_log2e - mx) + exp2f(v.z * scale_log2e - mx) + exp2f(v.w * scale_log2e - mx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const float4 v = *(const float4*)(row + c);
+        uint2 o;
+        o.x = pack_bf2(exp2f(v.x * scale_log2e - mx) * inv, exp2f(v.y * scale_log2e - mx) * inv);
+        o.y = pack_bf2(exp2f(v.z * scale_log2e - mx) * inv, exp2f(v.w * scale_log2e - mx) * inv);
+        *(uint2*)(out + c) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) affine_clamp_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                           float scale, float shift, float lo, float hi) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        y[i] = fminf(fmaxf(x[i] * scale + shift, lo), hi);
+}
+
 // ------------------------------------------------------------------------------ concat
 __global__ void __launch_bounds__(256) concat_kernel(const uint4* __restrict__ X1, int v1, const uint4* __restrict__ X2, int v2,
                                                      uint4* __restrict__ Y, int64_t rows) {
@@ -256,10 +301,12 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
 // workgroup = 64 consecutive output pixels x all Cout; lane = pixel (its 3x3xCIN patch lives in registers), wave q
 // owns a quarter of the output channels; the fp32 OHWI weights are staged once per workgroup in LDS and read as
 // wave-uniform broadcasts.  fp32 math (the latent is not rounded to bf16 before the first convolution).
+struct PreMap { float w[16]; float b[4]; int on; };
+
 template <int CIN>
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                      int B, int H, int W, int Cout) {
+                                                      int B, int H, int W, int Cout, const PreMap pm) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];        // [Cout][9*CIN]
     constexpr int KK = 9 * CIN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -278,9 +325,19 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
         for (int kx = 0; kx < 3; ++kx) {
             const int iy = oy + ky - 1, ix = ox + kx - 1;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            float v[CIN];
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci)
-                patch[(ky * 3 + kx) * CIN + ci] = ok ? x[(((int64_t)b * CIN + ci) * H + iy) * W + ix] : 0.f;
+            for (int ci = 0; ci < CIN; ++ci) v[ci] = ok ? x[(((int64_t)b * CIN + ci) * H + iy) * W + ix] : 0.f;
+            if (pm.on && CIN == 4) {          // per-pixel linear map of the latent; padding stays exactly zero
+                float u[4];
+#pragma unroll
+                for (int co = 0; co < 4; ++co)
+                    u[co] = ok ? pm.b[co] + pm.w[co * 4 + 0] * v[0] + pm.w[co * 4 + 1] * v[1] + pm.w[co * 4 + 2] * v[2] + pm.w[co * 4 + 3] * v[3] : 0.f;
+#pragma unroll
+                for (int co = 0; co < 4; ++co) v[co] = u[co];
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) patch[(ky * 3 + kx) * CIN + ci] = v[ci];
         }
     __syncthreads();
     const int cpq = Cout / 4;                      // output channels per wave (multiple of 8)
@@ -390,6 +447,24 @@ extern "C" int tmix_concat_channels(const void* X1, int C1, const void* X2, int 
     return TMIX_OK;
 }
 
+extern "C" int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale, void* stream) {
+    if (!S || !P) TMIX_FAIL(TMIX_EINVAL, "softmax_rows: null pointer");
+    if (rows <= 0 || cols <= 0 || (cols % 4) || (ld_s % 4) || (ld_p % 4)) TMIX_FAIL(TMIX_ESHAPE, "softmax_rows: rows=%lld cols=%d (cols, ld %% 4 == 0)", (long long)rows, cols);
+    if (!aligned16(S) || (((uintptr_t)P) & 7)) TMIX_FAIL(TMIX_EALIGN, "softmax_rows: pointer alignment");
+    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream) {
+    if (!x || !y) TMIX_FAIL(TMIX_EINVAL, "affine_clamp: null pointer");
+    if (n <= 0) TMIX_FAIL(TMIX_ESHAPE, "affine_clamp: empty");
+    int64_t nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+    affine_clamp_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(x, y, n, scale, shift, lo, hi);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
 extern "C" int tmix_timestep_embedding(const float* values, float* out, int count, int dim, void* stream) {
     if (!values || !out) TMIX_FAIL(TMIX_EINVAL, "timestep_embedding: null pointer");
     if (count <= 0 || dim <= 0 || (dim & 1)) TMIX_FAIL(TMIX_ESHAPE, "timestep_embedding: count=%d dim=%d", count, dim);
@@ -413,6 +488,11 @@ extern "C" int tmix_linear_small(const float* in, const void* W, const float* bi
 
 extern "C" int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
                             int B, int Cin, int H, int W, int Cout, void* stream) {
+    return tmix_conv_in_pre(x_nchw, w_ohwi, bias, y_nhwc, B, Cin, H, W, Cout, nullptr, nullptr, stream);
+}
+
+extern "C" int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
+                                int B, int Cin, int H, int W, int Cout, const float* pre_w, const float* pre_b, void* stream) {
     if (!x_nchw || !w_ohwi || !y_nhwc) TMIX_FAIL(TMIX_EINVAL, "conv_in: null pointer");
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv_in: bad shape");
     if (!aligned16(y_nhwc)) TMIX_FAIL(TMIX_EALIGN, "conv_in: output must be 16-byte aligned");
@@ -422,9 +502,21 @@ extern "C" int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const floa
     const int64_t npix = (int64_t)B * H * W;
     const unsigned nb = (unsigned)((npix + 63) / 64);
     const int smem = Cout * 36 * 4;
-    if (smem > 64 * 1024) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d too large for the LDS weight stage", Cout);
+    if (smem > 150 * 1024) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d too large for the LDS weight stage", Cout);
+    static int attr_smem = 0;
+    if (smem > 64 * 1024 && smem > attr_smem) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_in_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_smem = smem;
+    }
+    PreMap pm = {};
+    if (pre_w) {
+        pm.on = 1;
+        for (int i = 0; i < 16; ++i) pm.w[i] = pre_w[i];
+        for (int i = 0; i < 4; ++i) pm.b[i] = pre_b ? pre_b[i] : 0.f;
+    }
     hipStream_t st = (hipStream_t)stream;
-    conv_in_kernel<4><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout);
+    conv_in_kernel<4><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
