@@ -224,16 +224,22 @@ def main():
         imgs = M.random_rectangle_masks(K, args.res, args.res, seed=7)
         tw.mask_provider = lambda x0: (tw.masks if S > 1 else M.build_masks(imgs, tw.h, tw.w, device))
         xT = torch.randn(S, 4, tw.h, tw.w, generator=seed_gen)
+        from tweediemix_amd import vae as V
+        tw.vae = (V.FULL, V.synthetic_state_dict(V.FULL, device=device))     # random-init decoder of the SDXL VAE shapes
         tw.unet_calls.clear()
-        tw.run_fusion(xT.clone())                       # builds/captures the start and plain plans too
+        tw.run_fusion(xT.clone(), decode=True)          # builds/captures the start / plain / VAE plans too
         torch.cuda.synchronize()
         n_calls = len(tw.unet_calls)
         t1 = time.perf_counter()
-        out = tw.run_fusion(xT.clone())
+        lat = tw.run_fusion(xT.clone())
         torch.cuda.synchronize()
         dtt = time.perf_counter() - t1
-        assert torch.isfinite(out).all()
+        img = tw.decode_final(lat)
+        torch.cuda.synchronize()
+        dti = time.perf_counter() - t1
+        assert torch.isfinite(lat).all() and torch.isfinite(img).all()
         traj = {"trajectory_steps_per_s": 50 * S / dtt, "seconds_per_image": dtt / S, "unet_calls_per_image": n_calls,
+                "images_per_s_incl_vae_decode": S / dti, "vae_decode_ms": 1e3 * (dti - dtt) / S,
                 "calls_B4": sum(1 for c in tw.unet_calls[n_calls:] if c[1] == K + 1), "calls_B2": sum(1 for c in tw.unet_calls[n_calls:] if c[1] == 2)}
     if rank == 0:
         roof = gemm_roofline(plan)

@@ -224,3 +224,32 @@ def test_cli_drop_in_flags(tmp_path):
     lat2 = fs.main(argv + ["--t_stop", "0.8"])
     fs.LORA = False
     assert torch.isfinite(lat2).all()
+
+
+def test_sidecar_file_contract_and_decode(tmp_path):
+    """mask acquisition through the reference's file contract: tweedie.jpg out, '<concept>.jpg' masks in
+    (fusion_sampling.py:453-469), with a stand-in segmentation command; then the final VAE decode."""
+    need_gpu()
+    import sys
+    from tweediemix_amd import masks as M, sampler as S, vae as V
+    K, n, h, w = 3, 10, 16, 16
+    _orc, W, te, ts = _tiny_setup("custom", K, n, h, w)
+    fake = tmp_path / "fake_seg.py"
+    fake.write_text(
+        "import sys, os, numpy as np\nfrom PIL import Image\n"
+        "inp, cond, out = sys.argv[1:4]\nim = np.array(Image.open(inp))\nassert im.shape == (128, 128, 3)\n"
+        "for i, c in enumerate(cond.split('+')):\n"
+        "    m = np.zeros((128, 128), np.uint8); m[16:80, 8 + 56 * i: 56 + 56 * i] = 255\n"
+        "    Image.fromarray(m).save(os.path.join(out, c + '.jpg'))\n")
+    cfg = S.make_config(guidance_scale=0.8, n_timesteps=n, t_cond=0.2, resampling_steps=1, jumping_steps=1,
+                        resolution_h=h * 8, resolution_w=w * 8)
+    vae_sd = V.synthetic_state_dict(V.TINY, nontrivial=True)
+    tw = S.Tweediemix(cfg, W, te, ts, None, concept_num=K, vae=(V.TINY, vae_sd))
+    tw.mask_provider = M.SidecarMaskProvider(tw, str(tmp_path), "a cat+a dog", seg_gpu=0,
+                                             cmd_template=sys.executable + " " + str(fake) + " {input_path} \"{text_condition}\" {output_path}")
+    torch.manual_seed(1)
+    img = tw.run_fusion(torch.randn(1, 4, h, w), decode=True)
+    assert (tmp_path / "tweedie.jpg").exists() and (tmp_path / "a cat.jpg").exists() and (tmp_path / "a dog.jpg").exists()
+    assert tw.masks.shape == (K, 1, h, w) and tw.masks[:2].sum() > 0 and tw.masks[2].sum() > 0
+    assert float((tw.masks.sum(0) - 1).abs().max()) == 0.0          # disjoint rectangles + background = 1 everywhere
+    assert img.shape == (1, 3, h * 8, w * 8) and torch.isfinite(img).all() and 0.0 <= float(img.min()) and float(img.max()) <= 1.0

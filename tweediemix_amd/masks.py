@@ -47,3 +47,32 @@ def random_rectangle_masks(K: int, H: int, W: int, seed: int = 0):
         m[y0:y0 + hh, x0:x0 + ww] = 255
         out.append(m)
     return out
+
+
+class SidecarMaskProvider:
+    """The reference's segmentation side-car contract (fusion_sampling.py:453-469): decode the Tweedie preview,
+    save `{output_path}/tweedie.jpg`, run an external command that writes `{output_path}/{seg_concept}.jpg`
+    (8-bit masks; `text_segment/run_expand.py` in the reference), read them back through preprocess_mask.
+    cmd_template may use {input_path}, {text_condition}, {output_path}, {seg_gpu}."""
+
+    DEFAULT_CMD = ('CUDA_VISIBLE_DEVICES={seg_gpu} python text_segment/run_expand.py --input_path={input_path} '
+                   '--text_condition="{text_condition}" --output_path={output_path}')
+
+    def __init__(self, sampler, output_path, seg_concepts, seg_gpu=1, cmd_template=None):
+        self.sampler, self.output_path, self.seg_concepts, self.seg_gpu = sampler, output_path, seg_concepts, seg_gpu
+        self.cmd_template = cmd_template or self.DEFAULT_CMD
+
+    def __call__(self, x0_preview):
+        import os
+        from PIL import Image
+        os.makedirs(self.output_path, exist_ok=True)
+        img = self.sampler.decode_latent(x0_preview[:1])[0]                       # [3,H,W] in [0,1]
+        arr = (img.clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()   # ToPILImage semantics (mul 255, byte)
+        path = os.path.join(self.output_path, "tweedie.jpg")
+        Image.fromarray(arr).save(path)
+        cmd = self.cmd_template.format(input_path=path, text_condition=self.seg_concepts, output_path=self.output_path,
+                                       seg_gpu=self.seg_gpu)
+        os.system(cmd)                                                           # return code ignored, like the reference
+        paths = [os.path.join(self.output_path, sp + ".jpg") for sp in self.seg_concepts.split("+")]
+        s = self.sampler
+        return build_masks(paths, s.h, s.w, s.device)

@@ -66,7 +66,7 @@ class Tweediemix:
 
     def __init__(self, config, weights: UNetWeights, text_embeds, text_embeds_single, mask_provider,
                  concept_num: int, lora: bool = False, strict_reference: bool = True, use_graphs: bool = False,
-                 n_seeds: int = 1, n_streams: int = 1):
+                 n_seeds: int = 1, n_streams: int = 1, vae=None):
         self.config = config
         self.W = weights
         self.device = weights.device
@@ -79,6 +79,9 @@ class Tweediemix:
         self.n_seeds = int(n_seeds)
         # n_streams > 1 splits the rows of every UNet call into that many independent launch chains (PlanGroup)
         self.n_streams = int(n_streams)
+        # optional VAE decoder: (config, state_dict) of tweediemix_amd.vae -- enables decode_latent / decoded outputs
+        self.vae = vae
+        self._vae_plans = {}
         self.min_rows_per_stream = 1
         self.text_embeds = text_embeds
         self.text_embeds_single = text_embeds_single
@@ -161,6 +164,26 @@ class Tweediemix:
             p.run()
         return p.eps
 
+    # ------------------------------------------------------------------ VAE
+    def _decode(self, latent, inv_scale):
+        from .vae import VAEDecoderPlan
+        if self.vae is None:
+            raise L.TmixError("no VAE weights were given to Tweediemix(vae=(config, state_dict))")
+        key = (round(inv_scale, 6), latent.shape[0])
+        if key not in self._vae_plans:
+            self._vae_plans[key] = VAEDecoderPlan(self.vae[0], self.vae[1], latent.shape[0], self.h, self.w, inv_scale, self.device)
+        return self._vae_plans[key](latent)
+
+    @torch.no_grad()
+    def decode_latent(self, latent):
+        """fusion_sampling.py:297-303: the PREVIEW decode, with the reference's 1/0.18215 scale (not SDXL's 0.13025)."""
+        return self._decode(latent, 1 / 0.18215)
+
+    @torch.no_grad()
+    def decode_final(self, latent):
+        """fusion_sampling.py:496-524: x / vae.config.scaling_factor (0.13025) -> decoder -> (img/2+0.5).clamp(0,1)."""
+        return self._decode(latent, 1 / 0.13025)
+
     # ------------------------------------------------------------------ phases
     def init_fusion(self, t_cond, t_stop=None):
         ts = self.scheduler.timesteps
@@ -238,7 +261,7 @@ class Tweediemix:
                                           for i in range(self.n_seeds)]).contiguous()
         return out
 
-    def run_fusion(self, x=None):
+    def run_fusion(self, x=None, decode=False):
         cfg = self.config
         t_cond = int(cfg.n_timesteps * cfg.t_cond)
         if self.lora:
@@ -247,11 +270,12 @@ class Tweediemix:
             self.init_fusion(t_cond)
         if x is None:      # drawn on the CPU like the reference (fusion_sampling.py:488): device-independent seeds
             x = torch.randn(self.n_seeds, 4, self.h, self.w) * self.scheduler.init_noise_sigma
-        return self.sample_loop(x.to(self.device, F32))
+        return self.sample_loop(x.to(self.device, F32), decode=decode)
 
     @torch.no_grad()
-    def sample_loop(self, x):
-        """runs every scheduler timestep; returns the final latent (VAE decode is a 'next' row)."""
+    def sample_loop(self, x, decode=False):
+        """runs every scheduler timestep; returns the final latent, or the decoded image [n,3,H,W] in [0,1] when
+        decode=True and VAE weights were given (fusion_sampling.py:496-528)."""
         for t in self.scheduler.timesteps:
             x = self.denoise_step(x, t).clone()
-        return x
+        return self.decode_final(x) if decode else x
