@@ -1,0 +1,67 @@
+"""CPU: host-side logic that needs no GPU -- schedule tables and masks of the product package against the golden
+vectors, parameter inventories, CLI flag surface, tile/plan bookkeeping."""
+import os
+
+import numpy as np
+import torch
+
+
+def test_product_schedule_matches_golden(golden_dir):
+    from tweediemix_amd.schedule import Schedule
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    for n in (20, 50):
+        s = Schedule(n)
+        assert s.timesteps == [int(v) for v in g[f"timesteps_{n}"]]
+        assert all(np.float32(s.alpha(t)) == a for t, a in zip(s.timesteps, g[f"alpha_{n}"]))
+        assert all(np.float32(s.alpha(t - s.skip)) == a for t, a in zip(s.timesteps, g[f"alpha_next_{n}"]))
+    assert Schedule(50).alpha(-19) == Schedule(50).final_alpha_cumprod
+
+
+def test_product_masks_match_golden(golden_dir):
+    from tweediemix_amd import masks as M
+    g = np.load(os.path.join(golden_dir, "masks.npz"))
+    for hw in (128, 64):
+        m = M.build_masks([g["img_a_cat"], g["img_a_dog"]], hw, hw, device="cpu")
+        assert np.array_equal(m.numpy(), g[f"masks_all_{hw}"])
+    r = M.random_rectangle_masks(3, 256, 256, seed=1)
+    assert len(r) == 2 and all(0.08 < (a > 0).mean() < 0.35 for a in r)
+
+
+def test_parameter_inventories():
+    from tweediemix_amd import unet as U, vae as V, weights as Wt
+    n = sum(int(np.prod(s)) for s in Wt.param_shapes(U.SDXL).values())
+    assert n == 2_567_463_684                                  # SDXL-base UNet
+    assert len(U.attention_blocks(U.SDXL)) == 70
+    assert sum(int(np.prod(s)) for s in V.param_shapes(V.FULL).values()) == 49_490_199
+    sd = Wt.synthetic_state_dict(U.TINY)
+    assert set(sd) == set(Wt.param_shapes(U.TINY))
+    c = Wt.synthetic_concepts(U.TINY, "lora", 2)
+    assert all(v.shape[0] == 4 or v.shape[1] == 4 for v in c[0].values())     # rank 4 (model_lora.py:28-48)
+
+
+def test_cli_flag_surface():
+    """every flag of the reference's argparse block (fusion_sampling.py:534-585, + --t_stop in the LoRA script)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fs_cli_cpu", os.path.join(root, "fusion_generation", "fusion_sampling.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
+    ref_flags = ["seed", "device", "output_path", "output_path_all", "negative_prompt", "sd_version", "t_cond", "guidance_scale",
+                 "n_timesteps", "prompt", "prompt_orig", "seg_concepts", "personal_checkpoint", "concepts", "modifier_token",
+                 "resampling_steps", "jumping_steps", "seg_gpu", "crops_coords_top_left_h", "crops_coords_top_left_w",
+                 "resolution_h", "resolution_w"]
+    opt = fs.build_parser().parse_args([])
+    for f in ref_flags:
+        assert hasattr(opt, f), f
+    assert (opt.seed, opt.t_cond, opt.guidance_scale, opt.n_timesteps, opt.resampling_steps, opt.jumping_steps) == (182, 0.4, 9.0, 50, 10, 5)
+    fs.LORA = True
+    assert fs.build_parser().parse_args([]).t_stop == 0.9
+    fs.LORA = False
+
+
+def test_geglu_interleave_is_a_permutation():
+    from tweediemix_amd.weights import interleave_geglu
+    w = torch.arange(64 * 4, dtype=torch.float32).reshape(64, 4)
+    wi, _ = interleave_geglu(w, None)
+    assert sorted(wi[:, 0].tolist()) == w[:, 0].tolist()
+    assert wi[0, 0] == w[0, 0] and wi[16, 0] == w[32, 0] and wi[32, 0] == w[16, 0]     # [value 0-15 | gate 0-15 | value 16-31 ...]
