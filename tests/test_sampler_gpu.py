@@ -119,8 +119,8 @@ def _tiny_setup(kind, K=3, n=10, h=16, w=16, seed=0):
     return orc, W, te, ts
 
 
-@pytest.mark.parametrize("kind,graphs", [("custom", False), ("lora", False), ("custom", True)])
-def test_end_to_end_vs_oracle_sampler(kind, graphs):
+@pytest.mark.parametrize("kind,graphs,streams", [("custom", False, 1), ("lora", False, 1), ("custom", True, 1), ("lora", True, 2)])
+def test_end_to_end_vs_oracle_sampler(kind, graphs, streams):
     """whole trajectory (start/resampling, plain, jumping, fusion, t==1) on the tiny UNet.
     Tolerances (bf16-activation UNet vs the fp32 oracle on identical weights):
       teacher-forced (each step started from the oracle's latent): rel L2 <= 2e-2 per step (6e-2 for the
@@ -136,7 +136,7 @@ def test_end_to_end_vs_oracle_sampler(kind, graphs):
     cfg = S.make_config(guidance_scale=0.8, n_timesteps=n, t_cond=0.2, t_stop=0.8, resampling_steps=2, jumping_steps=2,
                         resolution_h=h * 8, resolution_w=w * 8)
     tw = S.Tweediemix(cfg, W, te, ts, lambda x0: M.build_masks(imgs, h, w), concept_num=K, lora=(kind == "lora"),
-                      use_graphs=graphs)
+                      use_graphs=graphs, n_streams=streams)
     torch.manual_seed(5)
     xT = torch.randn(1, 4, h, w)
     out = tw.run_fusion(xT.clone()).cpu()
