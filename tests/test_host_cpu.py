@@ -65,3 +65,19 @@ def test_geglu_interleave_is_a_permutation():
     wi, _ = interleave_geglu(w, None)
     assert sorted(wi[:, 0].tolist()) == w[:, 0].tolist()
     assert wi[0, 0] == w[0, 0] and wi[16, 0] == w[32, 0] and wi[32, 0] == w[16, 0]     # [value 0-15 | gate 0-15 | value 16-31 ...]
+
+
+def test_expand_masks_matches_reference_sidecar(golden_dir):
+    """bounding-rectangle + overlap rule of text_segment/run_expand.py:35-87, against what the reference script
+    itself saved (oracle/gen_golden_masks.py ran it with prepared SAM masks)."""
+    from oracle import tweedie_oracle as TO
+    from tweediemix_amd import masks as M
+    g = np.load(os.path.join(golden_dir, "expand_masks.npz"))
+    for case in ("disjoint", "overlap", "contained", "touching"):
+        ins = [g[f"{case}_in0"], g[f"{case}_in1"]]
+        for impl in (M.expand_masks, TO.expand_masks):
+            out = impl(ins)
+            for i in range(2):
+                assert np.array_equal(out[i], g[f"{case}_out{i}"].astype(bool)), (case, i, impl.__module__)
+    # >80 % rule fired in the 'contained' case: mask 1 lost the overlap box, mask 0 kept only its original pixels there
+    assert g["contained_out0"].sum() == g["contained_in0"].sum()

@@ -49,6 +49,34 @@ def random_rectangle_masks(K: int, H: int, W: int, seed: int = 0):
     return out
 
 
+def expand_masks(masks):
+    """The side-car's post-processing of the two SAM masks (text_segment/run_expand.py:35-87): every mask becomes its
+    bounding rectangle; where the two rectangles overlap, the bounding box of the overlap is re-filled with the
+    ORIGINAL masks restricted to the overlap, and mask 1 loses it entirely when more than 80 % of original mask 0
+    lies inside the overlap.  Like the reference this handles exactly two foreground masks (:62); for any other
+    count only the rectangles are produced.  masks: list of bool arrays [H,W]; returns list of bool arrays."""
+    import numpy as np
+    orig = [np.asarray(m).astype(bool) for m in masks]
+    rect = []
+    for m in orig:
+        ys, xs = np.nonzero(m)
+        r = np.zeros_like(m)
+        r[ys.min():ys.max() + 1, xs.min():xs.max() + 1] = True
+        rect.append(r)
+    if len(rect) == 2:
+        ov = rect[0] & rect[1]
+        if ov.any():
+            ys, xs = np.nonzero(ov)
+            y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+            o1 = ov & orig[0]
+            o2 = ov & orig[1]
+            if o1.sum() / orig[0].sum() > 0.8:
+                o2 = np.zeros_like(o2)
+            rect[0][y0:y1, x0:x1] = o1[y0:y1, x0:x1]
+            rect[1][y0:y1, x0:x1] = o2[y0:y1, x0:x1]
+    return rect
+
+
 class SidecarMaskProvider:
     """The reference's segmentation side-car contract (fusion_sampling.py:453-469): decode the Tweedie preview,
     save `{output_path}/tweedie.jpg`, run an external command that writes `{output_path}/{seg_concept}.jpg`
