@@ -84,8 +84,25 @@ typedef struct {
     int32_t M, N, K, batch;
     int32_t epilogue;
     int32_t tile_cfg;                            /* TMIX_TILE_AUTO or a specific tiling (autotuned by the host) */
+    /* --- LayerNorm fused across the GEMM pair that surrounds it (diffusers BasicTransformerBlock.norm1/2/3):
+     * producer: row_stats_out[b][t][m] = {sum, sum of squares} over the columns of column-tile t of the STORED
+     *   (bf16-rounded) output row m: plain stores in a fixed reduction order (no atomics, nothing to zero, replays are
+     *   bit-reproducible).  t < tmix_gemm_stats_parts(N, tile_cfg); tile_cfg must be explicit (not TMIX_TILE_AUTO).
+     * consumer: A holds the raw (un-normalised) rows and ln_stats the producer's ln_parts partials per row; with
+     *   W' = W*gamma (column-scaled), ln_colsum[n] = sum_k W'[n][k] and bias[n] = sum_k W[n][k]*beta[k] (+ the layer's
+     *   bias) the kernel forms  rstd[m] * (acc[m][n] - mean[m] * ln_colsum[n]) + bias[n]  ==  Linear(LayerNorm(x)).
+     * Statistics live as fp32 {sum, sumsq} pairs [parts][ld rows]; batch b of a batched GEMM starts stride floats in
+     * (so a [B*S]-row buffer serves both the flat M = B*S GEMMs and the batched M = S ones: ld = B*S, stride = 2*S). */
+    float* row_stats_out; int64_t strideStatsOut, ldStatsOut;     /* NULL or fp32 [parts][ldStatsOut][2] */
+    const float* ln_stats; int64_t strideLnStats, ldLnStats;      /* NULL or fp32 [ln_parts][ldLnStats][2] */
+    const float* ln_colsum; int64_t strideLnColsum;   /* fp32 [batch?][N] (stride 0: shared) */
+    float ln_inv_c, ln_eps;                           /* 1/C and eps of the LayerNorm */
+    int32_t ln_parts, reserved0;                      /* partials per row in ln_stats, 1..16 */
 } tmix_gemm_desc;
 int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
+/* workgroup tile of a TMIX_TILE_* id (bm x bn), and the number of row-statistics partials a GEMM of width N writes with it */
+int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn);
+int tmix_gemm_stats_parts(int N, int tile_cfg);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3 convolution, NHWC bf16, implicit GEMM on MFMA (pad 1).
@@ -142,6 +159,8 @@ int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y,
                         void* stream);
 int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta, int64_t rows, int C,
                    float eps, void* stream);
+/* hipMemsetAsync(ptr, 0, nbytes) on the stream (graph-capturable): zeroes the LayerNorm statistics accumulators */
+int tmix_zero(void* ptr, int64_t nbytes, void* stream);
 int tmix_concat_channels(const void* X1, int C1, const void* X2, int C2, void* Y, int64_t rows, void* stream);
 /* sinusoidal embedding (flip_sin_to_cos=True, shift 0): out[i] = [cos(v_i f_j) | sin(v_i f_j)], j<dim/2 */
 int tmix_timestep_embedding(const float* values, float* out, int count, int dim, void* stream);

@@ -35,7 +35,8 @@ def test_descriptor_layouts():
     assert lib.GemmDesc.rowgroup_bias.offset == 112 and lib.GemmDesc.rows_per_group.offset == 120
     assert lib.GemmDesc.Ct.offset == 128 and lib.GemmDesc.n_trans_begin.offset == 152
     assert lib.GemmDesc.M.offset == 156 and lib.GemmDesc.epilogue.offset == 172 and lib.GemmDesc.tile_cfg.offset == 176
-    assert ctypes.sizeof(lib.GemmDesc) == 184
+    assert lib.GemmDesc.row_stats_out.offset == 184 and lib.GemmDesc.ln_stats.offset == 208 and lib.GemmDesc.ln_colsum.offset == 232
+    assert lib.GemmDesc.ln_inv_c.offset == 248 and lib.GemmDesc.ln_parts.offset == 256 and ctypes.sizeof(lib.GemmDesc) == 264
     assert lib.ConvDesc.B.offset == 48 and lib.ConvDesc.tile_cfg.offset == 72 and ctypes.sizeof(lib.ConvDesc) == 80
 
 

@@ -276,3 +276,47 @@ def test_concat_and_embedding_and_linear_small(ops):
         y = ops.linear_small(x, w, bias, add, act_in=True, act_out=True)
         ref = F.silu(F.silu(x) @ w.float().T + bias + add)
         torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 7])
+def test_gemm_fused_layernorm_pair(ops, cfg):
+    """producer GEMM emits row statistics of what it stored, consumer GEMM applies LayerNorm algebraically:
+    together == Linear2(LayerNorm(Linear1(a) + res)) of diffusers' BasicTransformerBlock."""
+    from tweediemix_amd import lib as L
+    from tweediemix_amd.weights import fold_layernorm, interleave_geglu
+    import ctypes as C
+    M, C1, N2 = 300, 256, 384
+    a = rnd(M, C1, seed=70)
+    w1 = rnd(C1, C1, seed=71, scale=C1 ** -0.5)
+    b1 = rnd(C1, seed=72, dtype=torch.float32)
+    res = rnd(M, C1, seed=73) * 2 + 0.7                      # non-zero row means
+    gamma = rnd(C1, seed=74, dtype=torch.float32) * 0.2 + 1
+    beta = rnd(C1, seed=75, dtype=torch.float32) * 0.3
+    w2 = rnd(N2, C1, seed=76, scale=C1 ** -0.5)
+    b2 = rnd(N2, seed=77, dtype=torch.float32)
+    parts = ops.stats_parts(C1, cfg)
+    stats = torch.full((parts, M, 2), float("nan"), device="cuda")       # every slot must be written, none accumulated
+    h = ops.gemm(a, w1, bias=b1, residual=res, row_stats_out=stats, tile_cfg=cfg)
+    hf = h.float()
+    torch.testing.assert_close(stats[:, :, 0].sum(0), hf.sum(-1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(stats[:, :, 1].sum(0), (hf ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+    wp, cs, t = fold_layernorm(w2, gamma, beta, b2)
+    y = ops.gemm(h, wp, bias=t, ln_stats=stats, ln_colsum=cs, tile_cfg=cfg)
+    ref = F.layer_norm(hf, (C1,), gamma, beta, 1e-5) @ w2.float().T + b2
+    close(y, ref, rtol=2 ** -6, atol_frac=4e-3)
+    # GEGLU consumer and transposed-V consumer
+    w3 = rnd(8 * C1, C1, seed=78, scale=C1 ** -0.5)
+    b3 = rnd(8 * C1, seed=79, dtype=torch.float32)
+    wp3, cs3, t3 = fold_layernorm(w3, gamma, beta, b3)
+    wi = interleave_geglu(wp3, None)[0]
+    csi, ti = interleave_geglu(cs3[:, None], t3)
+    yg = ops.gemm(h, wi, bias=ti, geglu=True, ln_stats=stats, ln_colsum=csi[:, 0].contiguous(), tile_cfg=cfg)
+    z = F.layer_norm(hf, (C1,), gamma, beta, 1e-5) @ w3.float().T + b3
+    close(yg, z[:, :4 * C1] * F.gelu(z[:, 4 * C1:]), rtol=2 ** -6, atol_frac=4e-3)
+    w4 = rnd(3 * C1, C1, seed=80, scale=C1 ** -0.5)
+    wp4, cs4, t4 = fold_layernorm(w4, gamma, beta, None)
+    vt = torch.zeros(1, C1, 304, device="cuda", dtype=BF)
+    qk = ops.gemm(h.unsqueeze(0), wp4, bias=t4, out_t=vt, n_trans_begin=2 * C1, ln_stats=stats, ln_colsum=cs4, tile_cfg=cfg)
+    z4 = F.layer_norm(hf, (C1,), gamma, beta, 1e-5) @ w4.float().T
+    close(qk[0], z4[:, :2 * C1], rtol=2 ** -6, atol_frac=4e-3)
+    close(vt[0, :, :M], z4[:, 2 * C1:].T, rtol=2 ** -6, atol_frac=4e-3)

@@ -24,6 +24,11 @@ namespace {
 constexpr int BK = 64;
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
+__device__ __forceinline__ float xor32_sum(float x) {      // x + (value of lane ^ 32)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct Params {
     const bf16_t* A; int64_t lda, strideA;
     const bf16_t* W; int64_t ldw, strideW;
@@ -34,6 +39,9 @@ struct Params {
     bf16_t* Ct; int64_t ldct, strideCt; int n_trans_begin;
     int M, N, K, tiles_m, tiles_n, group_m, epilogue;
     unsigned bytesA, bytesW;          // extents of one batch slice (buffer bounds)
+    float* stats_out; int64_t strideStatsOut, ldStatsOut;      // LayerNorm producer side: float2 [tiles_n][ld] partial sums
+    const float* ln_stats; int64_t strideLnStats, ldLnStats; const float* ln_colsum; int64_t strideLnColsum;   // consumer side
+    float ln_inv_c, ln_eps; int ln_parts;
     // convolution geometry (CONV only)
     int H, Wd, Cin, Ho, Wo, mode;
 };
@@ -145,6 +153,58 @@ gemm_conv_kernel(const Params p) {
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < 9) conv_tap_offsets(); } }
     };
 
+    // ---- fused LayerNorm (consumer side), part 1: the producer GEMM left ln_parts partial {sum, sum of squares}
+    // per row (one per column tile of ITS grid).  Thread t owns tile row t and tile column t: the partials (added in
+    // a fixed order -> scheduling-independent) and the weight column sum are requested here, and reduced once the
+    // prologue's K-tiles are in flight (ln_reduce), so their latency rides under the prologue.  The results go to a
+    // small LDS block behind the staging ring, already in MFMA-operand form (see part 2).
+    uint4* ln_mfrag = (uint4*)(smem + NS * STAGE);    // [BM] -mean pieces, [BN] colsum pieces, then float rstd[BM]
+    uint4* ln_cfrag = ln_mfrag + BM;
+    float* ln_rs = (float*)(ln_cfrag + BN);
+    constexpr int PU = 16;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x2 lnv[PU];
+    float ln_cs = 0.f;
+    const bool ln_on = p.ln_stats != nullptr;
+    if (ln_on) {
+        // buffer loads: the per-lane offset is the row, the partial index rides in the scalar offset
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ln_stats + (int64_t)bz * p.strideLnStats), 0,
+                                                                              (int)(p.ln_parts * p.ldLnStats * 8), 0x00020000);
+        if (tid < BM) {
+            const int lnm = min(m0 + tid, p.M - 1);
+#pragma unroll
+            for (int q = 0; q < PU; ++q)
+                if (q < p.ln_parts) lnv[q] = __builtin_amdgcn_raw_buffer_load_b64(rsS, lnm * 8, q * (int)p.ldLnStats * 8, 0);
+        }
+        if (tid < BN) ln_cs = (p.ln_colsum + (int64_t)bz * p.strideLnColsum)[min(n0 + tid, p.N - 1)];
+    }
+    // x = x1 + x2 + x3 (bf16 pieces by truncation, exact residuals): operand halves {x1,x1,x2,0 | x1,x3,x2,0} for -mean
+    // and {x1,x2,x1,0 | x3,x1,x2,0} for colsum pair up to the six products x_a * y_b with a + b <= 4 (~24 bits)
+    auto ln_reduce = [&]() {
+        if (!ln_on) return;
+        if (tid < BM) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < PU; ++q)
+                if (q < p.ln_parts) { s1 += __uint_as_float(lnv[q].x); s2 += __uint_as_float(lnv[q].y); }
+            const float mean = s1 * p.ln_inv_c;
+            ln_rs[tid] = rsqrtf(fmaxf(s2 * p.ln_inv_c - mean * mean, 0.f) + p.ln_eps);
+            const float x = -mean;
+            const unsigned x1 = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(x1);
+            const unsigned x2 = __float_as_uint(r1) & 0xffff0000u;
+            const unsigned x3 = __float_as_uint(r1 - __uint_as_float(x2)) & 0xffff0000u;
+            ln_mfrag[tid] = make_uint4((x1 >> 16) | x1, x2 >> 16, (x1 >> 16) | x3, x2 >> 16);
+        }
+        if (tid < BN) {
+            const unsigned x1 = __float_as_uint(ln_cs) & 0xffff0000u;
+            const float r1 = ln_cs - __uint_as_float(x1);
+            const unsigned x2 = __float_as_uint(r1) & 0xffff0000u;
+            const unsigned x3 = __float_as_uint(r1 - __uint_as_float(x2)) & 0xffff0000u;
+            ln_cfrag[tid] = make_uint4((x1 >> 16) | x2, x1 >> 16, (x3 >> 16) | x1, x2 >> 16);
+        }
+    };
+
     f32x16 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -193,6 +253,7 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
+    ln_reduce();
     if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -228,7 +289,41 @@ gemm_conv_kernel(const Params p) {
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 
-    // ---------------------------------------------------------------- epilogue
+    // ---------------------------------------------------------------- fused LayerNorm (consumer side), part 2
+    // A was the raw row x; with W' = W*gamma:  Linear(LN(x))[m][n] = rstd_m * (acc[m][n] - mean_m * colsum_n) + t_n
+    // (t_n arrives as the bias).  The rank-1 term -mean_m * colsum_n is one more MFMA k-step per fragment, fed from
+    // the operand pieces ln_reduce left in LDS (visible: every wave has passed >= 2 barriers since); rstd_m is
+    // applied as the multiplier of the bias FMA in the epilogue.
+    float rs_row[FM];                                 // row-major tiles: rstd of this lane's row per fragment
+#pragma unroll
+    for (int i = 0; i < FM; ++i) rs_row[i] = 1.f;
+    if (p.ln_stats) {
+        // fragments follow the LDS sources of the main loop: a[i] <- rows of off_a's tile, b[j] <- rows of off_b's
+        const uint2* srcA = (const uint2*)(ln_mfrag + wr * TM + l31) + lhi;
+        const uint2* srcW = (const uint2*)(ln_cfrag + wc * TN + l31) + lhi;
+        const uint2* src_a = trans ? srcW : srcA;
+        const uint2* src_b = trans ? srcA : srcW;
+        frag_ab fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const uint2 h = src_a[i * 64];
+            uint4 u = make_uint4(h.x, h.y, 0u, 0u);
+            fa[i] = *(frag_ab*)&u;
+            if (!trans) rs_row[i] = ln_rs[wr * TM + i * 32 + l31];
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const uint2 h = src_b[j * 64];
+            uint4 u = make_uint4(h.x, h.y, 0u, 0u);
+            fb[j] = *(frag_ab*)&u;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+
     // 32x32 accumulator: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
     if (trans) {
@@ -244,16 +339,20 @@ gemm_conv_kernel(const Params p) {
                 for (int j = 0; j < FN; ++j)               // A fragment (4 consecutive m per register group)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int m = m0 + wr * TM + j * 32 + g * 8 + lhi * 4;
+                        const int ml = wr * TM + j * 32 + g * 8 + lhi * 4, m = m0 + ml;
                         if (m >= p.M) continue;
+                        const float4 rs = p.ln_stats ? *(const float4*)(ln_rs + ml) : make_float4(1.f, 1.f, 1.f, 1.f);
+                        const float o0 = fmaf(acc[i][j][g * 4 + 0], rs.x, bv), o1 = fmaf(acc[i][j][g * 4 + 1], rs.y, bv);
+                        const float o2 = fmaf(acc[i][j][g * 4 + 2], rs.z, bv), o3 = fmaf(acc[i][j][g * 4 + 3], rs.w, bv);
                         if (m + 3 < p.M && ((p.ldct & 3) == 0)) {
                             uint2 v;
-                            v.x = pack_bf2(acc[i][j][g * 4 + 0] + bv, acc[i][j][g * 4 + 1] + bv);
-                            v.y = pack_bf2(acc[i][j][g * 4 + 2] + bv, acc[i][j][g * 4 + 3] + bv);
+                            v.x = pack_bf2(o0, o1);
+                            v.y = pack_bf2(o2, o3);
                             *(uint2*)(row + m) = v;
                         } else {
+                            const float o[4] = {o0, o1, o2, o3};
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) if (m + r < p.M) row[m + r] = f2bf(acc[i][j][g * 4 + r] + bv);
+                            for (int r = 0; r < 4; ++r) if (m + r < p.M) row[m + r] = f2bf(o[r]);
                         }
                     }
             }
@@ -280,7 +379,8 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
-                        if (bias) { a += bias[nv + r]; gt += bias[nv + 16 + r]; }
+                        if (bias) { a = fmaf(a, rs_row[i], bias[nv + r]); gt = fmaf(gt, rs_row[i], bias[nv + 16 + r]); }
+                        else { a *= rs_row[i]; gt *= rs_row[i]; }
                         o[r] = a * gelu_erf_f(gt);
                     }
                     uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
@@ -290,10 +390,16 @@ gemm_conv_kernel(const Params p) {
         }
         return;
     }
+    // LayerNorm producer side: {sum, sum of squares} of every row of this tile AS STORED (bf16-rounded), reduced over
+    // the wave's fragments, the lane pair and the WG's wave columns in a fixed order, then written (not accumulated)
+    // to stats_out[tile_n][m] -- one partial per column tile; the consumer adds the tiles_n partials.
+    float2* sto = p.stats_out ? (float2*)(p.stats_out + (int64_t)bz * p.strideStatsOut) : nullptr;
+    float2* red = (float2*)smem;                                // [WN][BM]: the staging ring is free by now
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wr * TM + i * 32 + l31;
-        if (m >= p.M) continue;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < p.M) {
         const float* rg = p.rgb ? p.rgb + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
 #pragma unroll
         for (int j = 0; j < FN; ++j)
@@ -304,7 +410,10 @@ gemm_conv_kernel(const Params p) {
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[i][j][g * 4 + r];
-                if (bias) { const float4 b4 = *(const float4*)(bias + n); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+                if (bias) { const float4 b4 = *(const float4*)(bias + n);
+                            o[0] = fmaf(o[0], rs_row[i], b4.x); o[1] = fmaf(o[1], rs_row[i], b4.y);
+                            o[2] = fmaf(o[2], rs_row[i], b4.z); o[3] = fmaf(o[3], rs_row[i], b4.w); }
+                else if (p.ln_stats) { o[0] *= rs_row[i]; o[1] *= rs_row[i]; o[2] *= rs_row[i]; o[3] *= rs_row[i]; }
                 if (rg)   { const float4 b4 = *(const float4*)(rg + n);   o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
                 if (Rb) {
                     uint2 rv;
@@ -318,8 +427,28 @@ gemm_conv_kernel(const Params p) {
                 } else {
                     uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
                     *(uint2*)(Cb + (int64_t)m * p.ldc + n) = v;
+                    if (sto) {
+                        const float r0 = __uint_as_float(v.x << 16), r1 = __uint_as_float(v.x & 0xffff0000u);
+                        const float r2 = __uint_as_float(v.y << 16), r3 = __uint_as_float(v.y & 0xffff0000u);
+                        s1 += (r0 + r1) + (r2 + r3);
+                        s2 = fmaf(r0, r0, s2); s2 = fmaf(r1, r1, s2); s2 = fmaf(r2, r2, s2); s2 = fmaf(r3, r3, s2);
+                    }
                 }
             }
+        }
+        if (sto) {                                     // wave-uniform; lanes l and l^32 hold the two halves of row m
+            s1 = xor32_sum(s1); s2 = xor32_sum(s2);
+            if (!lhi) red[wc * BM + wr * TM + i * 32 + l31] = make_float2(s1, s2);
+        }
+    }
+    if (sto) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float2 t = red[tid];
+#pragma unroll
+            for (int c = 1; c < WN; ++c) { const float2 u = red[c * BM + tid]; t.x += u.x; t.y += u.y; }
+            sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
+        }
     }
 }
 
@@ -336,7 +465,7 @@ constexpr int NUM_CFG = 7;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
-    constexpr int SMEM = NS * (BM + BN) * 128;
+    constexpr int SMEM = NS * (BM + BN) * 128 + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
     static bool attr_set = false;   // idempotent; racing threads set the same value
     auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV>;
     if (!attr_set) {
@@ -377,6 +506,19 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
+    static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160}};
+    if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
+    *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
+    return TMIX_OK;
+}
+
+extern "C" int tmix_gemm_stats_parts(int N, int tile_cfg) {
+    int bm, bn;
+    if (N <= 0 || tmix_gemm_tile_shape(tile_cfg, &bm, &bn) != TMIX_OK) return -1;
+    return (N + bn - 1) / bn;
+}
+
 extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W) TMIX_FAIL(TMIX_EINVAL, "gemm: null descriptor/operand");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) TMIX_FAIL(TMIX_ESHAPE, "gemm: empty problem M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
@@ -408,6 +550,14 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     p.epilogue = d->epilogue;
     p.bytesA = (unsigned)(((int64_t)(d->M - 1) * d->lda + d->K) * 2);
     p.bytesW = (unsigned)(((int64_t)(d->N - 1) * d->ldw + d->K) * 2);
+    if (d->row_stats_out && (has_trans || d->epilogue != TMIX_EPI_NONE)) TMIX_FAIL(TMIX_EINVAL, "gemm: row_stats_out needs the plain bf16 epilogue");
+    if (d->row_stats_out && (d->tile_cfg < 1 || d->tile_cfg > NUM_CFG || (((uintptr_t)d->row_stats_out) & 7) || (d->strideStatsOut & 1) || d->ldStatsOut < d->M))
+        TMIX_FAIL(TMIX_EINVAL, "gemm: row_stats_out needs an explicit tile_cfg (its partial count depends on it) and 8-byte alignment");
+    if (d->ln_stats && (!d->ln_colsum || !(d->ln_inv_c > 0.f) || d->ln_parts < 1 || d->ln_parts > 16 || (int64_t)d->ln_parts * d->ldLnStats * 8 >= (1ll << 31) || (((uintptr_t)d->ln_stats) & 7) || (d->strideLnStats & 1) || d->ldLnStats < d->M))
+        TMIX_FAIL(TMIX_EINVAL, "gemm: fused LayerNorm needs ln_colsum, ln_inv_c > 0, 1 <= ln_parts <= 16 and 8-byte aligned ln_stats (< 2 GiB)");
+    p.stats_out = d->row_stats_out; p.strideStatsOut = d->strideStatsOut; p.ldStatsOut = d->ldStatsOut;
+    p.ln_stats = d->ln_stats; p.strideLnStats = d->strideLnStats; p.ldLnStats = d->ldLnStats; p.ln_parts = d->ln_parts;
+    p.ln_colsum = d->ln_colsum; p.strideLnColsum = d->strideLnColsum; p.ln_inv_c = d->ln_inv_c; p.ln_eps = d->ln_eps;
     return launch<0>(p, d->batch, d->tile_cfg, (hipStream_t)stream);
 }
 

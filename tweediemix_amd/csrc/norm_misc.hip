@@ -437,6 +437,13 @@ extern "C" int tmix_layernorm(const void* X, void* Y, const float* gamma, const 
     return TMIX_OK;
 }
 
+extern "C" int tmix_zero(void* ptr, int64_t nbytes, void* stream) {
+    if (!ptr || nbytes <= 0) TMIX_FAIL(TMIX_EINVAL, "zero: null pointer / empty range");
+    hipError_t e = hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) TMIX_FAIL((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return TMIX_OK;
+}
+
 extern "C" int tmix_concat_channels(const void* X1, int C1, const void* X2, int C2, void* Y, int64_t rows, void* stream) {
     if (!X1 || !X2 || !Y) TMIX_FAIL(TMIX_EINVAL, "concat: null pointer");
     if (rows <= 0 || C1 <= 0 || C2 <= 0 || (C1 % 8) || (C2 % 8)) TMIX_FAIL(TMIX_ESHAPE, "concat: rows=%lld C1=%d C2=%d unsupported", (long long)rows, C1, C2);

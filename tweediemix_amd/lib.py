@@ -31,7 +31,11 @@ class GemmDesc(C.Structure):
                 ("Ct", vp), ("ldct", i64), ("strideCt", i64),
                 ("n_trans_begin", i32),
                 ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
-                ("epilogue", i32), ("tile_cfg", i32)]
+                ("epilogue", i32), ("tile_cfg", i32),
+                ("row_stats_out", vp), ("strideStatsOut", i64), ("ldStatsOut", i64),
+                ("ln_stats", vp), ("strideLnStats", i64), ("ldLnStats", i64),
+                ("ln_colsum", vp), ("strideLnColsum", i64), ("ln_inv_c", f32), ("ln_eps", f32),
+                ("ln_parts", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -60,6 +64,9 @@ SIGNATURES = {
     "tmix_groupnorm_nhwc": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, C.c_int, f32,
                                       C.c_int, vp]),
     "tmix_layernorm": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, f32, vp]),
+    "tmix_zero": (C.c_int, [vp, i64, vp]),
+    "tmix_gemm_tile_shape": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tmix_gemm_stats_parts": (C.c_int, [C.c_int, C.c_int]),
     "tmix_concat_channels": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, i64, vp]),
     "tmix_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "tmix_linear_small": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

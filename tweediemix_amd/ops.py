@@ -61,8 +61,16 @@ def fused_tweedie_step(x, eps, masks, mode, K, g, at, at_next, is_last=False, ou
     return out_x
 
 
+def stats_parts(N, tile_cfg):
+    """number of row-statistics partials a GEMM of width N writes with tiling tile_cfg (tmix_gemm_stats_parts)."""
+    n = L.load().tmix_gemm_stats_parts(int(N), int(tile_cfg))
+    assert n > 0, (N, tile_cfg)
+    return n
+
+
 def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows_per_group=0, geglu=False,
-                   out_t=None, n_trans_begin=-1, tile_cfg=0):
+                   out_t=None, n_trans_begin=-1, tile_cfg=0, row_stats_out=None, ln_stats=None, ln_colsum=None,
+                   ln_eps=1e-5, ln_parts=0):
     """a [batch?,M,K] bf16 (last dim contiguous), w [batch?,N,K] bf16, out [batch?,M,N'] bf16."""
     a3 = a if a.dim() == 3 else a.unsqueeze(0)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -97,6 +105,20 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
     d.M, d.N, d.K, d.batch = M, N, K, batch
     d.epilogue = L.EPI_GEGLU if geglu else L.EPI_NONE
     d.tile_cfg = tile_cfg
+    if row_stats_out is not None:          # fp32 [parts, rows, 2] per-column-tile partial sums, rows = batch*M
+        st = row_stats_out
+        assert st.dtype == torch.float32 and st.is_contiguous() and st.dim() == 3 and st.shape[1:] == (batch * M, 2)
+        assert tile_cfg > 0 and st.shape[0] >= stats_parts(N, tile_cfg)
+        d.row_stats_out, d.strideStatsOut, d.ldStatsOut = st.data_ptr(), 2 * M, st.shape[1]
+    if ln_stats is not None:               # fused LayerNorm on the A rows (see include/tmix.h)
+        st = ln_stats
+        assert st.dtype == torch.float32 and st.is_contiguous() and st.dim() == 3 and st.shape[1:] == (batch * M, 2)
+        assert ln_colsum is not None and ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous()
+        assert ln_colsum.shape in ((N,), (batch, N))
+        d.ln_stats, d.strideLnStats, d.ldLnStats = st.data_ptr(), 2 * M, st.shape[1]
+        d.ln_parts = int(ln_parts) if ln_parts else st.shape[0]
+        d.ln_colsum, d.strideLnColsum = ln_colsum.data_ptr(), (N if ln_colsum.dim() == 2 and batch > 1 else 0)
+        d.ln_inv_c, d.ln_eps = 1.0 / K, ln_eps
     return d
 
 

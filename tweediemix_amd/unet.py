@@ -25,7 +25,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .weights import interleave_geglu
+from .weights import fold_layernorm, interleave_geglu
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -132,11 +132,17 @@ class UNetWeights:
                 rows.append(rows[0] + up @ dn)
             return torch.stack(rows)
 
+        def fold(key, w, norm, bias=None):
+            """store Linear(LayerNorm(.)) folded for tmix_gemm_desc.ln_*: W*gamma, its column sums and W@beta (+bias)."""
+            wp, cs, tt = fold_layernorm(w.to(dev, F32), g(norm + ".weight"), g(norm + ".bias"), bias)
+            t[key], t[key + ".colsum"], t[key + ".bias"] = wp, cs, tt
+
         for tb, _c in attention_blocks(cfg):
             a1, a2 = tb + ".attn1", tb + ".attn2"
-            t[a1 + ".qkv"] = bf(torch.cat([g(a1 + ".to_q.weight"), g(a1 + ".to_k.weight"), g(a1 + ".to_v.weight")]))
+            n1, n2, n3 = tb + ".norm1", tb + ".norm2", tb + ".norm3"
+            fold(a1 + ".qkv", torch.cat([g(a1 + ".to_q.weight"), g(a1 + ".to_k.weight"), g(a1 + ".to_v.weight")]), n1)
             t[a1 + ".out"] = bf(g(a1 + ".to_out.0.weight"))
-            t[a2 + ".q"] = bf(g(a2 + ".to_q.weight"))
+            fold(a2 + ".q", g(a2 + ".to_q.weight"), n2)
             t[a2 + ".out"] = bf(g(a2 + ".to_out.0.weight"))
             kv_rows = [torch.cat([g(a2 + ".to_k.weight"), g(a2 + ".to_v.weight")]).to(F32)]
             if custom is not None:                      # row 1+i: concept i's to_k / to_v (utils_custom.py:66-80)
@@ -146,16 +152,18 @@ class UNetWeights:
                 mk = merged(g(a2 + ".to_k.weight"), a2, "k")
                 mv = merged(g(a2 + ".to_v.weight"), a2, "v")
                 kv_rows = [torch.cat([mk[i], mv[i]]) for i in range(mk.shape[0])]
-                t[a1 + ".qkv_rows"] = bf(torch.cat([merged(g(a1 + ".to_q.weight"), a1, "q"),
-                                                    merged(g(a1 + ".to_k.weight"), a1, "k"),
-                                                    merged(g(a1 + ".to_v.weight"), a1, "v")], dim=1))
+                fold(a1 + ".qkv_rows", torch.cat([merged(g(a1 + ".to_q.weight"), a1, "q"),
+                                                  merged(g(a1 + ".to_k.weight"), a1, "k"),
+                                                  merged(g(a1 + ".to_v.weight"), a1, "v")], dim=1), n1)
                 t[a1 + ".out_rows"] = bf(merged(g(a1 + ".to_out.0.weight"), a1, "out"))
-                t[a2 + ".q_rows"] = bf(merged(g(a2 + ".to_q.weight"), a2, "q"))
+                fold(a2 + ".q_rows", merged(g(a2 + ".to_q.weight"), a2, "q"), n2)
                 t[a2 + ".out_rows"] = bf(merged(g(a2 + ".to_out.0.weight"), a2, "out"))
             t[a2 + ".kv_rows"] = bf(torch.stack(kv_rows))       # [1 or 1+K, 2C, cross]
-            wi, bi = interleave_geglu(g(tb + ".ff.net.0.proj.weight"), g(tb + ".ff.net.0.proj.bias"))
-            t[tb + ".ff1"] = bf(wi)
-            t[tb + ".ff1.bias"] = f32(bi)
+            wp, cs, tt = fold_layernorm(g(tb + ".ff.net.0.proj.weight").to(F32), g(n3 + ".weight"), g(n3 + ".bias"),
+                                        g(tb + ".ff.net.0.proj.bias"))
+            t[tb + ".ff1"] = interleave_geglu(wp, None)[0].contiguous()
+            csi, bi = interleave_geglu(cs[:, None], tt)
+            t[tb + ".ff1.colsum"], t[tb + ".ff1.bias"] = csi[:, 0].contiguous(), bi.contiguous()
         self.t = t
 
     def __getitem__(self, k):
@@ -226,17 +234,6 @@ class _Arena:
 _TUNE_CACHE = {}      # (kind, shape key) -> best TMIX_TILE_* id, shared by every plan in the process
 
 
-def _time_launch(fn, desc, stream, reps=4):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn(C.byref(desc), stream)
-    e0.record()
-    for _ in range(reps):
-        fn(C.byref(desc), stream)
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
-
-
 class UNetPlan:
     """One UNet call shape: batch B, latent h x w, a KV cache (prompt rows) and a routing flag.
 
@@ -277,37 +274,75 @@ class UNetPlan:
         torch.cuda.synchronize()
         self._gn_ws = ops.groupnorm_ws(B, 4096, cfg.norm_groups, dev)
         self._vt = {}
+        # LayerNorm row statistics travel from the GEMM that writes the hidden state to the GEMM behind the norm as
+        # per-column-tile partial sums [parts][B*S][2]; launches on one stream are ordered, so all sites share one buffer
+        nb = len(cfg.block_out_channels)
+        need = 1
+        for pfx, cc, _n in transformer_sites(cfg):
+            lvl = nb - 1 if pfx.startswith("mid") else int(pfx.split(".")[1]) if pfx.startswith("down") else nb - 1 - int(pfx.split(".")[1])
+            need = max(need, ((cc + 127) // 128) * B * (h >> lvl) * (w >> lvl) * 2)
+        self._ln_buf = torch.zeros(need, device=dev, dtype=F32)
+        self._tunable = []                  # (index into self.ops, kind, descriptor) of every GEMM / conv launch
+        self._ln_links = []                 # (producer desc, [consumer descs]): ln_parts follows the producer's tiling
         self._build()
+        self._link_ln()
         if autotune:
             self.autotune()
 
-    def autotune(self):
-        """pick the fastest workgroup tiling (TMIX_TILE_*) per distinct GEMM / conv shape by timing the
-        candidates on the device (the shapes of this path are small and awkward -- M=4096, N=1280 -- so
-        tile quantisation over 256 CUs, not peak MFMA rate, decides).  Descriptors are patched in place."""
+    @staticmethod
+    def _tune_key(kind, d):
+        if kind == "gemm":
+            return (kind, d.M, d.N, d.K, d.batch, d.epilogue, d.n_trans_begin >= 0, bool(d.residual), d.strideW != 0,
+                    bool(d.row_stats_out), bool(d.ln_stats))
+        return (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode)
+
+    def autotune(self, reps=3):
+        """pick the fastest workgroup tiling (TMIX_TILE_*) per distinct GEMM / conv shape (the shapes of this path are
+        small and awkward -- M=4096, N=1280 -- so tile quantisation over 256 CUs, not peak MFMA rate, decides).
+        Candidates are timed IN SITU: the whole forward runs once per candidate with every tunable launch bracketed by
+        events, so each launch sees the cache state it meets in the real sequence (weights cold from HBM, activations
+        fresh from the previous kernel); back-to-back replays of one launch rank the tilings differently and picked a
+        mix that lost 4 % to the best single tiling.  Descriptors are patched in place; choices are cached per shape."""
         import os
+        tun = [(i, kind, d) for i, kind, d in self._tunable]
         force = int(os.environ.get("TMIX_FORCE_TILE", "0"))          # debugging / sensitivity studies
         if force:
-            for kind in ("gemm", "conv"):
-                for d, _fl in self.launches[kind]:
-                    d.tile_cfg = force
+            for _i, _k, d in tun:
+                d.tile_cfg = force
+            self._link_ln()
             return
-        st = torch.cuda.current_stream().cuda_stream
-        for kind, fn in (("gemm", self.lib.tmix_gemm_bf16), ("conv", self.lib.tmix_conv3x3_nhwc)):
-            for d, _fl in self.launches[kind]:
-                if kind == "gemm":
-                    key = (kind, d.M, d.N, d.K, d.batch, d.epilogue, d.n_trans_begin >= 0, bool(d.residual), d.strideW != 0)
-                else:
-                    key = (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode)
-                best = _TUNE_CACHE.get(key)
-                if best is None:
-                    times = {}
-                    for cfg in range(1, L.TILE_COUNT + 1):
+        keys = [self._tune_key(kind, d) for _i, kind, d in tun]
+        if any(k not in _TUNE_CACHE for k in keys):
+            idx = {i: n for n, (i, _k, _d) in enumerate(tun)}
+            st = torch.cuda.current_stream().cuda_stream
+            best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
+            for _rep in range(reps):
+                for cfg in range(1, L.TILE_COUNT + 1):
+                    for _i, _k, d in tun:
                         d.tile_cfg = cfg
-                        times[cfg] = _time_launch(fn, d, st)
-                    best = min(times, key=times.get)
-                    _TUNE_CACHE[key] = best
-                d.tile_cfg = best
+                    self._link_ln()
+                    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in tun]
+                    for i, (fn, args) in enumerate(self.ops):
+                        n = idx.get(i)
+                        if n is not None:
+                            ev[n][0].record()
+                        rc = fn(*args, st)
+                        if rc:
+                            L.check(rc, fn.__name__)
+                        if n is not None:
+                            ev[n][1].record()
+                    torch.cuda.synchronize()
+                    tot = {}
+                    for n, k in enumerate(keys):
+                        tot[k] = tot.get(k, 0.0) + ev[n][0].elapsed_time(ev[n][1])
+                    for k, t in tot.items():
+                        best_t[(k, cfg)] = min(best_t.get((k, cfg), float("inf")), t)
+            for k in set(keys):
+                if k not in _TUNE_CACHE:
+                    _TUNE_CACHE[k] = min(range(1, L.TILE_COUNT + 1), key=lambda c: best_t[(k, c)])
+        for (_i, _kind, d), k in zip(tun, keys):
+            d.tile_cfg = _TUNE_CACHE[k]
+        self._link_ln()
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ op emitters
@@ -322,13 +357,20 @@ class UNetPlan:
         return out
 
     def _gemm(self, a, w, out, **kw):
+        if kw.get("row_stats_out") is not None:
+            kw.setdefault("tile_cfg", 1)            # the partial count depends on the tiling: never TMIX_TILE_AUTO
         d = ops.make_gemm_desc(a, w, out, **kw)
+        if kw.get("row_stats_out") is not None:
+            self._ln_links.append((d, []))
+        elif kw.get("ln_stats") is not None:
+            self._ln_links[-1][1].append(d)
         self.keep.append(d)
         self._emit(self.lib.tmix_gemm_bf16, C.byref(d))
         fl = 2 * d.M * d.N * d.K * d.batch
         self.flops += fl
         self.gemm_flops += fl
         self.launches["gemm"].append((d, fl))
+        self._tunable.append((len(self.ops) - 1, "gemm", d))
         return out
 
     def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None):
@@ -341,13 +383,20 @@ class UNetPlan:
         fl = 2 * self.B * Ho * Wo * Cout * 9 * Cin
         self.flops += fl
         self.launches["conv"].append((d, fl))
+        self._tunable.append((len(self.ops) - 1, "conv", d))
         return out
 
-    def _ln(self, x, name, rows, Cc):
-        out = self.arena.get(*x.shape)
-        self._emit(self.lib.tmix_layernorm, x.data_ptr(), out.data_ptr(), self.W[name + ".weight"].data_ptr(),
-                   self.W[name + ".bias"].data_ptr(), rows, Cc, 1e-5)
-        return out
+    def _ln_stats(self, S, Cc):
+        """fp32 [parts_max, B*S, 2] view of the shared row-statistics buffer for one LayerNorm site: written by the GEMM
+        that stores the hidden state (row_stats_out), read by the GEMM behind the norm (ln_stats)."""
+        pm = (Cc + 127) // 128
+        return self._ln_buf[:pm * self.B * S * 2].view(pm, self.B * S, 2)
+
+    def _link_ln(self):
+        for prod, cons in self._ln_links:
+            parts = ops.stats_parts(prod.N, prod.tile_cfg)
+            for c in cons:
+                c.ln_parts = parts
 
     def _attn(self, q, k, vt, out, H, Sq, Skv):
         args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
@@ -390,27 +439,32 @@ class UNetPlan:
             A.put(sc)
         return out
 
-    def _proj(self, a, key, out, S, Cin, **kw):
-        """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM."""
+    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, **kw):
+        """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM.
+        ln: statistics of a LayerNorm folded into this projection (weights stored folded, see UNetWeights.fold);
+        stats_out: accumulate the statistics of the rows this projection writes."""
         W = self.W
-        if self.routed:
-            return self._gemm(a.view(self.B, S, Cin), self._rows(key), out, **kw)
-        o2 = out.view(self.B * S, out.shape[-1]) if out is not None else None
-        for kk in ("residual",):
-            if kw.get(kk) is not None:
-                kw[kk] = kw[kk].view(self.B * S, kw[kk].shape[-1])
-        if kw.get("out_t") is not None:       # transposed V is per batch row -> keep the batch dimension
-            return self._gemm(a.view(self.B, S, Cin), W[key], out, **kw)
-        return self._gemm(a.view(self.B * S, Cin), W[key], o2, **kw)
+        batched = self.routed or kw.get("out_t") is not None    # transposed V is per batch row -> keep the batch dimension
+        shp = (self.B, S) if batched else (self.B * S,)
+        if ln is not None:
+            kw["ln_stats"] = ln
+            kw["ln_colsum"] = self._rows(key, ".colsum") if self.routed else W[key + ".colsum"]
+            kw["bias"] = self._rows(key, ".bias") if self.routed else W[key + ".bias"]
+        if stats_out is not None:
+            kw["row_stats_out"] = stats_out
+        if kw.get("residual") is not None:
+            kw["residual"] = kw["residual"].view(*shp, kw["residual"].shape[-1])
+        w = self._rows(key) if self.routed else W[key]
+        return self._gemm(a.view(*shp, Cin), w, out.view(*shp, out.shape[-1]), **kw)
 
-    def _rows(self, key):
+    def _rows(self, key, suffix=""):
         """[B, N, K] per-row weight sets for a routed projection (a view when rows are 0..K in order)."""
-        w = self.W[key + "_rows"]
+        w = self.W[key + "_rows" + suffix]
         if self.row_sets == list(range(w.shape[0])):
             return w
-        if key not in self._rows_cache:
-            self._rows_cache[key] = w[torch.tensor(self.row_sets, device=w.device)].contiguous()
-        return self._rows_cache[key]
+        if key + suffix not in self._rows_cache:
+            self._rows_cache[key + suffix] = w[torch.tensor(self.row_sets, device=w.device)].contiguous()
+        return self._rows_cache[key + suffix]
 
     def _t2d(self, x, Cc, Hh, Ww, name, n):
         B, W, A = self.B, self.W, self.arena
@@ -418,38 +472,36 @@ class UNetPlan:
         H = Cc // self.cfg.head_dim
         g = self._gn(x, Cc, S, name + ".norm", 1e-6, False)
         h = A.get(B, S, Cc)
-        self._gemm(g.view(B * S, Cc), W[name + ".proj_in.weight"], h.view(B * S, Cc), bias=W[name + ".proj_in.bias"])
+        st = self._ln_stats(S, Cc)
+        self._gemm(g.view(B * S, Cc), W[name + ".proj_in.weight"], h.view(B * S, Cc), bias=W[name + ".proj_in.bias"],
+                   row_stats_out=st if n else None)
         A.put(g)
         vt = self._vt_buf(Cc, S)
         for i in range(n):
             tb = f"{name}.transformer_blocks.{i}"
             a1, a2 = tb + ".attn1", tb + ".attn2"
-            # --- self attention
-            y = self._ln(h, tb + ".norm1", B * S, Cc)
+            # --- self attention; norm1 is folded into the q/k/v projection
             qk = A.get(B, S, 2 * Cc)
-            self._proj(y, a1 + ".qkv", qk, S, Cc, out_t=vt, n_trans_begin=2 * Cc)
-            A.put(y)
+            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc)
             ao = A.get(B, S, Cc)
             self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
             A.put(qk)
-            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h)
+            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st)
             A.put(ao)
-            # --- cross attention against the cached K / V^T
-            y = self._ln(h, tb + ".norm2", B * S, Cc)
+            # --- cross attention against the cached K / V^T; norm2 folded into to_q
             q = A.get(B, S, Cc)
-            self._proj(y, a2 + ".q", q, S, Cc)
-            A.put(y)
+            self._proj(h, a2 + ".q", q, S, Cc, ln=st)
             ao = A.get(B, S, Cc)
             self._attn(q, self.kv.k[a2], self.kv.vt[a2], ao, H, S, self.kv.Lk)
             A.put(q)
-            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h)
+            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st)
             A.put(ao)
-            # --- feed forward (GEGLU fused in the first GEMM's epilogue)
-            y = self._ln(h, tb + ".norm3", B * S, Cc)
+            # --- feed forward: norm3 folded into the first GEMM, GEGLU fused in its epilogue
             f = A.get(B * S, 4 * Cc)
-            self._gemm(y.view(B * S, Cc), W[tb + ".ff1"], f, bias=W[tb + ".ff1.bias"], geglu=True)
-            A.put(y)
-            self._gemm(f, W[tb + ".ff.net.2.weight"], h.view(B * S, Cc), bias=W[tb + ".ff.net.2.bias"], residual=h.view(B * S, Cc))
+            self._gemm(h.view(B * S, Cc), W[tb + ".ff1"], f, bias=W[tb + ".ff1.bias"], geglu=True,
+                       ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"])
+            self._gemm(f, W[tb + ".ff.net.2.weight"], h.view(B * S, Cc), bias=W[tb + ".ff.net.2.bias"], residual=h.view(B * S, Cc),
+                       row_stats_out=st if i + 1 < n else None)
             A.put(f)
         out = A.get(B, S, Cc)
         self._gemm(h.view(B * S, Cc), W[name + ".proj_out.weight"], out.view(B * S, Cc), bias=W[name + ".proj_out.bias"],

@@ -15,6 +15,19 @@ def interleave_geglu(w: torch.Tensor, b: torch.Tensor | None):
     return w[idx].contiguous(), (None if b is None else b[idx].contiguous())
 
 
+def fold_layernorm(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: torch.Tensor | None):
+    """Linear(LayerNorm(x)) with the norm's affine folded into the Linear (tmix_gemm_desc.ln_*):
+    returns (W' = W*gamma as bf16, colsum[n] = sum_k W'[n][k] of the bf16-rounded W', t[n] = W[n]·beta + bias[n]).
+    w may be [N,K] or a stack [R,N,K] of per-row weight sets."""
+    w32 = w.float()
+    wp = (w32 * gamma.float()).to(torch.bfloat16)
+    colsum = wp.float().sum(-1)
+    t = w32 @ beta.float()
+    if bias is not None:
+        t = t + bias.float()
+    return wp.contiguous(), colsum.contiguous(), t.contiguous()
+
+
 # ----------------------------------------------------------------------------------------------
 # parameter inventory (diffusers key scheme) and synthetic weights / concept deltas
 # ----------------------------------------------------------------------------------------------
