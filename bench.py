@@ -133,11 +133,7 @@ def gemm_concurrent(plan, reps=3):
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in subs[1:]]
     lists = [[(fn, a) for fn, a in p.ops if fn is lib.tmix_gemm_bf16] for p in subs]
     flops = sum(f for p in subs for _d, f in p.launches["gemm"])
-    best = None
-    for _ in range(reps):
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    def enqueue():
         fork = torch.cuda.Event(); fork.record()
         joins = []
         for ops_, st in zip(lists, streams):
@@ -148,6 +144,20 @@ def gemm_concurrent(plan, reps=3):
                 ev = torch.cuda.Event(); ev.record(st); joins.append(ev)
         for ev in joins:
             torch.cuda.current_stream().wait_event(ev)
+
+    # captured once and replayed, like the timed region: eager launches from Python (~20 us each) would serialise the chains
+    enqueue()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        streams[0] = torch.cuda.current_stream()
+        enqueue()
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)

@@ -19,6 +19,8 @@ allocation, so it can be captured into a hipGraph (torch.cuda.graphs) and replay
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from dataclasses import dataclass
 
 import torch
@@ -231,7 +233,27 @@ class _Arena:
             self.free.setdefault(buf.numel(), []).append(buf)
 
 
-_TUNE_CACHE = {}      # (kind, shape key) -> best TMIX_TILE_* id, shared by every plan in the process
+_TUNE_CACHE = {}      # repr((kind, shape key)) -> best TMIX_TILE_* id, shared by every plan in the process
+_TUNE_FILE = os.environ.get("TMIX_TUNE_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json"))
+
+
+def load_tune_table(path=None):
+    """seed the tiling cache from a JSON table {repr(shape key): TMIX_TILE_* id} measured on an MI355X by
+    tools/make_tune_table.py (the shipped tweediemix_amd/tuned_gfx950.json; TMIX_TUNE_FILE overrides, '' disables).
+    Shapes missing from the table are still timed in situ when a plan is built."""
+    path = _TUNE_FILE if path is None else path
+    if path and os.path.exists(path):
+        with open(path) as f:
+            _TUNE_CACHE.update({k: int(v) for k, v in json.load(f).items()})
+    return len(_TUNE_CACHE)
+
+
+def save_tune_table(path):
+    with open(path, "w") as f:
+        json.dump(dict(sorted(_TUNE_CACHE.items())), f, indent=0)
+
+
+load_tune_table()
 
 
 class UNetPlan:
@@ -292,18 +314,18 @@ class UNetPlan:
     @staticmethod
     def _tune_key(kind, d):
         if kind == "gemm":
-            return (kind, d.M, d.N, d.K, d.batch, d.epilogue, d.n_trans_begin >= 0, bool(d.residual), d.strideW != 0,
-                    bool(d.row_stats_out), bool(d.ln_stats))
-        return (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode)
+            return repr((kind, d.M, d.N, d.K, d.batch, d.epilogue, d.n_trans_begin >= 0, bool(d.residual), d.strideW != 0,
+                         bool(d.row_stats_out), bool(d.ln_stats)))
+        return repr((kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode))
 
-    def autotune(self, reps=3):
+    def autotune(self, reps=None):
         """pick the fastest workgroup tiling (TMIX_TILE_*) per distinct GEMM / conv shape (the shapes of this path are
         small and awkward -- M=4096, N=1280 -- so tile quantisation over 256 CUs, not peak MFMA rate, decides).
         Candidates are timed IN SITU: the whole forward runs once per candidate with every tunable launch bracketed by
         events, so each launch sees the cache state it meets in the real sequence (weights cold from HBM, activations
         fresh from the previous kernel); back-to-back replays of one launch rank the tilings differently and picked a
         mix that lost 4 % to the best single tiling.  Descriptors are patched in place; choices are cached per shape."""
-        import os
+        reps = reps or int(os.environ.get("TMIX_TUNE_REPS", "3"))
         tun = [(i, kind, d) for i, kind, d in self._tunable]
         force = int(os.environ.get("TMIX_FORCE_TILE", "0"))          # debugging / sensitivity studies
         if force:
