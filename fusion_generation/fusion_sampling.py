@@ -3,17 +3,22 @@
 
 Accepts the reference's argv unchanged (flags of fusion_sampling.py:534-585; `+`-separated lists, background
 concept last) and runs the same Tweedie-mix loop on the MI355X-native sampler.  What the reference does around
-the loop but this repository does not build (SURVEY 8f "next" rows) is replaced by explicit inputs:
+the loop through the HF hub (checkpoint download) takes local paths here:
 
+  --sd_path              local SDXL checkpoint in diffusers layout (unet/, text_encoder/, text_encoder_2/, tokenizer/,
+                         tokenizer_2/, optionally vae/): prompts are tokenised and encoded natively (tweediemix_amd/text.py,
+                         modifier tokens of --personal_checkpoint injected), the UNet comes from unet/
+  --vae_path             VAE folder or weights file (the reference uses madebyollin/sdxl-vae-fp16-fix); with a VAE the
+                         final image is written as {output_path_all}/{prompt_orig}_{seed}.png like the reference
   --unet_path            diffusers-format SDXL UNet weights (.safetensors / torch state dict); the concept
                          checkpoints of --personal_checkpoint (delta-*.bin, key 'unet') load unchanged
-  --text_embeds_path     torch file {'text_embeds': (E[K+2,77,2048], P[K+2,1280]),
-                                     'text_embeds_single': (E[K,77,2048], P[K,1280])}  (CLIP encoders are out of scope)
+  --text_embeds_path     precomputed embeddings instead of the text towers: torch file
+                         {'text_embeds': (E[K+2,77,2048], P[K+2,1280]), 'text_embeds_single': (E[K,77,2048], P[K,1280])}
   --mask_paths           '+'-separated 8-bit masks for the foreground concepts (what run_expand.py would write
                          as '<concept>.jpg'); --random_masks draws seeded rectangles instead
   --synthetic            random-init weights / embeddings of the SDXL shapes (no checkpoints exist offline)
 
-Output: {output_path_all}/{prompt_orig}_{seed}.latent.pt (the VAE decode to PNG is a "next" row).
+Output: {output_path_all}/{prompt_orig}_{seed}.latent.pt, plus the .png when VAE weights are given.
 """
 import argparse
 import os
@@ -57,6 +62,8 @@ def build_parser():
         p.add_argument('--t_stop', type=float, default=0.9)          # fusion_sampling_lora.py:547
     # --- additive flags
     p.add_argument('--synthetic', action='store_true')
+    p.add_argument('--sd_path', type=str, default='')
+    p.add_argument('--vae_path', type=str, default='')
     p.add_argument('--unet_path', type=str, default='')
     p.add_argument('--text_embeds_path', type=str, default='')
     p.add_argument('--mask_paths', type=str, default='')
@@ -76,6 +83,24 @@ def load_state_dict(path):
     return sd.get('state_dict', sd)
 
 
+def find_weights(folder, stem):
+    """first existing of {stem}.fp16.safetensors / {stem}.safetensors / {stem}.bin under folder (or folder itself if a file)."""
+    if os.path.isfile(folder):
+        return folder
+    for ext in ('.fp16.safetensors', '.safetensors', '.bin'):
+        fp = os.path.join(folder, stem + ext)
+        if os.path.exists(fp):
+            return fp
+    raise FileNotFoundError(f'no {stem}.[fp16.]safetensors/.bin under {folder}')
+
+
+def save_png(img, path):
+    """img [3,H,W] in [0,1] -> 8-bit PNG (image_processor.postprocess(..., 'pil') of fusion_sampling.py:526-527)."""
+    from PIL import Image
+    a = (img.clamp(0, 1).permute(1, 2, 0).float().cpu().numpy() * 255).round().astype('uint8')
+    Image.fromarray(a).save(path)
+
+
 def main(argv=None):
     opt = build_parser().parse_args(argv)
     from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
@@ -84,6 +109,9 @@ def main(argv=None):
     concepts = [c for c in opt.concepts.split('+') if c] or ['a', 'b', 'background']
     K = len(concepts)                                    # concept_num, background last (fusion_sampling.py:143-148)
     cfg = U.TINY if opt.tiny else U.SDXL
+    if opt.sd_path and os.path.exists(os.path.join(opt.sd_path, 'unet', 'config.json')):
+        import json
+        cfg = U.UNetConfig.from_diffusers(json.load(open(os.path.join(opt.sd_path, 'unet', 'config.json'))))
     kind = 'lora' if LORA else 'custom'
     S.seed_everything(opt.seed)
     if opt.synthetic:
@@ -93,13 +121,20 @@ def main(argv=None):
         te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g), torch.randn(K + 2, cfg.pooled_dim, generator=g))
         ts = (torch.randn(K, 77, cfg.cross_dim, generator=g), torch.randn(K, cfg.pooled_dim, generator=g))
     else:
-        if not (opt.unet_path and opt.text_embeds_path and opt.personal_checkpoint):
-            sys.exit("need --unet_path, --text_embeds_path and --personal_checkpoint (or --synthetic); "
-                     "HF hub download / CLIP text encoders are outside this repository's scope")
-        sd = load_state_dict(opt.unet_path)
-        con = [torch.load(p, map_location='cpu')['unet'] for p in opt.personal_checkpoint.split('+')]   # :156-157
-        emb = torch.load(opt.text_embeds_path, map_location='cpu')
-        te, ts = emb['text_embeds'], emb['text_embeds_single']
+        unet_file = opt.unet_path or (opt.sd_path and find_weights(os.path.join(opt.sd_path, 'unet'), 'diffusion_pytorch_model'))
+        if not (unet_file and (opt.text_embeds_path or opt.sd_path) and opt.personal_checkpoint):
+            sys.exit("need --personal_checkpoint and either --sd_path (local diffusers-layout SDXL checkpoint) or "
+                     "--unet_path + --text_embeds_path (or --synthetic); there is no HF hub download here")
+        sd = load_state_dict(unet_file)
+        sts = [torch.load(p, map_location='cpu') for p in opt.personal_checkpoint.split('+')]            # :156-157
+        con = [st['unet'] for st in sts]
+        if opt.text_embeds_path:
+            emb = torch.load(opt.text_embeds_path, map_location='cpu')
+            te, ts = emb['text_embeds'], emb['text_embeds_single']
+        else:
+            from tweediemix_amd import text as T
+            te, ts, K_text = T.TextPath(opt.sd_path, opt.device).embed(opt, sts)
+            assert K_text == K, (K_text, K)
     W = U.UNetWeights(cfg, sd, opt.device, (kind, con))
     h, w = opt.resolution_h // 8, opt.resolution_w // 8
     if opt.mask_paths:
@@ -108,8 +143,23 @@ def main(argv=None):
         fg = M.random_rectangle_masks(K, opt.resolution_h, opt.resolution_w, seed=opt.seed)
     else:   # the reference's file contract: the side-car wrote '<seg_concept>.jpg' under output_path (:461-466)
         fg = [os.path.join(opt.output_path, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
+    vae = None
+    vae_dir = opt.vae_path or (opt.sd_path and os.path.isdir(os.path.join(opt.sd_path, 'vae')) and os.path.join(opt.sd_path, 'vae'))
+    if vae_dir:
+        from tweediemix_amd import vae as V
+        vcfg = V.FULL
+        if os.path.isdir(vae_dir) and os.path.exists(os.path.join(vae_dir, 'config.json')):
+            import json
+            j = json.load(open(os.path.join(vae_dir, 'config.json')))
+            vcfg = dict(block_out_channels=tuple(j['block_out_channels']), layers_per_block=j.get('layers_per_block', 2),
+                        latent_channels=j.get('latent_channels', 4), out_channels=j.get('out_channels', 3),
+                        groups=j.get('norm_num_groups', 32))
+        vae = (vcfg, load_state_dict(find_weights(vae_dir, 'diffusion_pytorch_model')))
+    elif opt.synthetic and opt.tiny:
+        from tweediemix_amd import vae as V
+        vae = (V.TINY, V.synthetic_state_dict(V.TINY))
     tw = S.Tweediemix(opt, W, te, ts, lambda x0: M.build_masks(fg, h, w, opt.device), concept_num=K, lora=LORA,
-                      use_graphs=not opt.no_graphs, n_seeds=opt.num_seeds, n_streams=opt.streams)
+                      use_graphs=not opt.no_graphs, n_seeds=opt.num_seeds, n_streams=opt.streams, vae=vae)
     x = torch.randn(opt.num_seeds, 4, h, w)             # CPU draw after seed_everything, like :488
     lat = tw.run_fusion(x)
     os.makedirs(opt.output_path_all, exist_ok=True)
@@ -118,6 +168,12 @@ def main(argv=None):
         out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.latent.pt'
         torch.save(lat[i:i + 1].cpu(), out)
         print('saved', out)
+    if vae is not None:                                   # fusion_sampling.py:496-528
+        img = tw.decode_final(lat)
+        for i in range(opt.num_seeds):
+            out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.png'
+            save_png(img[i], out)
+            print('saved', out)
     return lat
 
 

@@ -66,7 +66,9 @@ int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, cons
  * strideW != 0 selects one weight set per batch row).
  * Requirements: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned pointers.
  */
-enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1, TMIX_EPI_F32OUT = 2 /* C is fp32 [M][ldc] (attention scores of the VAE) */ };
+enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1, TMIX_EPI_F32OUT = 2 /* C is fp32 [M][ldc] (attention scores of the VAE) */,
+       TMIX_EPI_GELU = 3 /* gelu(acc + bias), erf form (OpenCLIP-bigG MLP) */,
+       TMIX_EPI_QUICKGELU = 4 /* x * sigmoid(1.702 x) (CLIP-L MLP) */ };
 /* workgroup tilings of the MFMA mainloop (BM x BN, waves, LDS ring depth); AUTO = built-in heuristic */
 enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, TMIX_TILE_128x128_S4 = 3,
        TMIX_TILE_256x256_S2 = 4, TMIX_TILE_256x128_W4 = 5, TMIX_TILE_256x256_W4 = 6, TMIX_TILE_128x160_S2 = 7,
@@ -167,6 +169,10 @@ int tmix_timestep_embedding(const float* values, float* out, int count, int dim,
 /* row softmax: P[r][c] = softmax_c(scale * S[r][c]), S fp32 [rows][ld_s] -> P bf16 [rows][ld_p] (VAE mid-block attention,
  * single head of dim 512: scores come from tmix_gemm_bf16 with TMIX_EPI_F32OUT). */
 int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale, void* stream);
+/* causal variant for the CLIP text encoders (transformers CLIPAttention with the causal mask, fusion_sampling.py:43-68):
+ * S is a stack of [seq][cols] score blocks; row r sees columns <= r % seq, every other column (padding included) gets 0. */
+int tmix_softmax_rows_causal(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale,
+                             int seq, void* stream);
 /* y = clamp(x*scale + shift, lo, hi) on fp32 (image post-processing (img/2+0.5).clamp(0,1), fusion_sampling.py:302) */
 int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
 /* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 16.

@@ -81,3 +81,56 @@ def test_expand_masks_matches_reference_sidecar(golden_dir):
                 assert np.array_equal(out[i], g[f"{case}_out{i}"].astype(bool)), (case, i, impl.__module__)
     # >80 % rule fired in the 'contained' case: mask 1 lost the overlap box, mask 0 kept only its original pixels there
     assert g["contained_out0"].sum() == g["contained_in0"].sum()
+
+
+def test_clip_bpe_tokenizer_matches_transformers_vectors(golden_dir):
+    """tweediemix_amd/text.py ClipBPETokenizer against ids produced by transformers' CLIPTokenizer on the synthetic
+    vocabulary of tests/golden/clip_tok (oracle/gen_golden_tokenizer.py): case folding, whitespace, contractions,
+    digits, non-ASCII bytes, truncation to 77, both pad conventions, added modifier tokens."""
+    import json, os
+    from tweediemix_amd.text import ClipBPETokenizer
+    d = os.path.join(golden_dir, "clip_tok")
+    cases = json.load(open(os.path.join(d, "cases.json")))
+    vocab = json.load(open(os.path.join(d, "vocab.json")))
+    for c in cases:
+        tok = ClipBPETokenizer.from_pretrained(d)
+        tok.pad_token = c["pad_token"]
+        assert tok(c["texts"]).tolist() == c["ids_plain"]
+        n0 = len(tok)
+        assert n0 == len(vocab)
+        for t, want in zip(c["added"], c["added_ids"]):
+            assert tok.add_tokens(t) == 1 and tok.convert_tokens_to_ids(t) == want
+        assert tok.add_tokens(c["added"][0]) == 0 and len(tok) == c["len_after"]
+        assert [tok.tokenize(t) for t in c["texts"]] == c["tokens_added"]
+        ids = tok(c["texts"])
+        assert ids.shape == (len(c["texts"]), 77) and ids.tolist() == c["ids_added"]
+
+
+def test_prompt_assembly_and_token_injection_match_reference_vectors(golden_dir):
+    """text.assemble_prompts / inject_modifier_tokens against tests/golden/prompts.json, produced by executing the
+    reference's own statements (oracle/gen_golden_prompts.py): modifier token placement incl. the find() == -1 case,
+    prompts_single, new token ids in both vocabularies and the embedding rows they receive."""
+    import json, os, types
+    import torch
+    from tweediemix_amd import text as T
+
+    class Enc:                                   # the two methods inject_modifier_tokens uses of ClipTextEncoder
+        def __init__(self, n, d):
+            self.tok = torch.zeros(n, d)
+        resize_token_embeddings = T.ClipTextEncoder.resize_token_embeddings
+        set_token_embedding = T.ClipTextEncoder.set_token_embedding
+        dev, d = torch.device("cpu"), None
+
+    for c in json.load(open(os.path.join(golden_dir, "prompts.json"))):
+        a = c["args"]
+        prompts, single, K = T.assemble_prompts(a["prompt"], a["prompt_orig"], a["concepts"], a["modifier_token"])
+        assert prompts == c["prompts"] and single == c["prompts_single"] and K == c["concept_num"]
+        sts = [{"modifier_token": {name: torch.tensor(v1)}, "modifier_token_2": {name: torch.tensor(v2)}} for name, v1, v2 in c["ckpt_tokens"]]
+        toks = [T.ClipBPETokenizer({f"t{i}": i for i in range(50)}, []), T.ClipBPETokenizer({f"t{i}": i for i in range(60)}, [])]
+        encs = [Enc(50, 8), Enc(60, 12)]
+        encs[0].d, encs[1].d = 8, 12
+        ids, ids_2 = T.inject_modifier_tokens(toks, encs, sts, a["modifier_token"].split('+'))
+        assert ids == c["ids"] and ids_2 == c["ids_2"]
+        torch.testing.assert_close(encs[0].tok[50:], torch.tensor(c["table_rows"]))
+        torch.testing.assert_close(encs[1].tok[60:], torch.tensor(c["table_rows_2"]))
+    assert T.inject_modifier_tokens(toks, encs, [{"unet": {}}], ["<x>"]) == ([], [])        # no 'modifier_token' in sts[0]: untouched

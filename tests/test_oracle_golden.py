@@ -132,3 +132,29 @@ def test_lora_merged_equivalence(golden_dir):
         y = O.sa_forward_lora(x[i + 1:i + 2], None, mw["q"], mw["k"], mw["v"], mw["out"], g[f"{p}_bo"], [],
                               heads=2, scale=64 ** -0.5, routed=False)
         np.testing.assert_allclose(y[0], g[f"{p}_B4_in_y"][i + 1], rtol=1e-4, atol=1e-4)
+
+
+def _clip_case(name, golden_dir):
+    import torch
+    z = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    src = "g" if name == "e" else name
+    sd = {k[len(src) + 4:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith(src + ".sd.")}
+    heads, eos, gelu, _n = [int(v) for v in z[name + ".meta"]]
+    return z, sd, heads, eos, ("gelu" if gelu else "quick_gelu")
+
+
+@pytest.mark.parametrize("name", ["l", "g", "e"])
+def test_clip_oracle_matches_transformers_vectors(name, golden_dir):
+    """oracle/clip_oracle.py against outputs of the transformers CLIP text models (tests/golden/clip_text.npz):
+    hidden_states[-2], final-norm output and the pooled / projected row for both pooled-position rules."""
+    import torch
+    from oracle import clip_oracle as CO
+    z, sd, heads, eos, act = _clip_case(name, golden_dir)
+    ids = torch.from_numpy(z[name + ".ids"])
+    o = CO.clip_text_forward(sd, ids, heads, act, eos_token_id=eos)
+    torch.testing.assert_close(o["hidden_states"][-2], torch.from_numpy(z[name + ".hs_m2"]), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(o["last_hidden_state"], torch.from_numpy(z[name + ".last"]), rtol=1e-4, atol=2e-5)
+    pooled = o["text_embeds"] if o["text_embeds"] is not None else o["pooler_output"]
+    torch.testing.assert_close(pooled, torch.from_numpy(z[name + ".pooled"]), rtol=1e-4, atol=2e-5)
+    if name == "g":          # legacy eos_token_id == 2: the pooled row sits at the largest id (the added token), not at EOS
+        assert int(ids[1].argmax()) == 3 and int(ids[2].argmax()) == 7

@@ -253,3 +253,84 @@ def test_sidecar_file_contract_and_decode(tmp_path):
     assert tw.masks.shape == (K, 1, h, w) and tw.masks[:2].sum() > 0 and tw.masks[2].sum() > 0
     assert float((tw.masks.sum(0) - 1).abs().max()) == 0.0          # disjoint rectangles + background = 1 everywhere
     assert img.shape == (1, 3, h * 8, w * 8) and torch.isfinite(img).all() and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
+
+
+def test_cli_sd_path_prompts_to_png(tmp_path, golden_dir):
+    """the whole drop-in on a synthetic diffusers-layout checkpoint folder: tokenizer + both text towers + modifier-token
+    injection (tweediemix_amd/text.py) -> UNet loop -> VAE decode -> '{prompt_orig}_{seed}.png' (fusion_sampling.py:139-196,
+    485-528).  The embeddings the CLI computes are checked against oracle/clip_oracle.py on the same ids."""
+    need_gpu()
+    import importlib.util, json, shutil
+    import os as _os
+    import numpy as np
+    from safetensors.torch import save_file
+    from tweediemix_amd import text as T, unet as U, vae as V, weights as Wt
+    from oracle import clip_oracle as CO
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    sdp = tmp_path / "sdxl"
+    z = np.load(_os.path.join(golden_dir, "clip_text.npz"))
+    g = torch.Generator().manual_seed(11)
+    towers = {}
+    for folder, name, act in (("text_encoder", "l", "quick_gelu"), ("text_encoder_2", "g", "gelu")):
+        sd = {k[len(name) + 4:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith(name + ".sd.")}
+        key = [k for k in sd if k.endswith("token_embedding.weight")][0]
+        sd[key] = torch.cat([sd[key], torch.randn(620 - 64, 128, generator=g) * 0.05])      # the tokenizer fixture has 615 ids
+        (sdp / folder).mkdir(parents=True)
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(sdp / folder / "model.safetensors"))
+        json.dump({"hidden_act": act, "num_attention_heads": 2, "eos_token_id": 2, "layer_norm_eps": 1e-5},
+                  open(sdp / folder / "config.json", "w"))
+        towers[folder] = (sd, 2, act, 2)
+    for folder, pad in (("tokenizer", "<|endoftext|>"), ("tokenizer_2", "!")):
+        shutil.copytree(_os.path.join(golden_dir, "clip_tok"), sdp / folder)
+        json.dump({"pad_token": pad}, open(sdp / folder / "special_tokens_map.json", "w"))
+    ucfg = {"block_out_channels": [64, 128, 256], "layers_per_block": 2, "transformer_layers_per_block": [1, 1, 2],
+            "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"], "attention_head_dim": [1, 2, 4],
+            "cross_attention_dim": 256, "addition_time_embed_dim": 32, "projection_class_embeddings_input_dim": 96 + 6 * 32}
+    cfg = U.UNetConfig.from_diffusers(ucfg)
+    assert cfg.transformer_layers == (0, 1, 2) and cfg.pooled_dim == 96 and cfg.cross_dim == 256
+    (sdp / "unet").mkdir()
+    json.dump(ucfg, open(sdp / "unet" / "config.json", "w"))
+    save_file({k: v.cpu().contiguous() for k, v in Wt.synthetic_state_dict(cfg, seed=3, device="cpu", dtype=torch.float16).items()},
+              str(sdp / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    (sdp / "vae").mkdir()
+    json.dump({"block_out_channels": list(V.TINY["block_out_channels"]), "layers_per_block": V.TINY["layers_per_block"]},
+              open(sdp / "vae" / "config.json", "w"))
+    save_file({k: v.cpu().contiguous() for k, v in V.synthetic_state_dict(V.TINY, nontrivial=True).items()},
+              str(sdp / "vae" / "diffusion_pytorch_model.safetensors"))
+    ckpts = []
+    for i, con in enumerate(Wt.synthetic_concepts(cfg, "custom", 3, device="cpu")):
+        fp = tmp_path / f"delta{i}.bin"
+        torch.save({"unet": con, "modifier_token": {f"<new{i + 1}>": torch.randn(128, generator=g) * 0.1},
+                    "modifier_token_2": {f"<new{i + 1}>": torch.randn(128, generator=g) * 0.1}}, fp)
+        ckpts.append(str(fp))
+    spec = importlib.util.spec_from_file_location("fs_cli2", _os.path.join(root, "fusion_generation", "fusion_sampling.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
+    argv = ["--sd_path", str(sdp), "--personal_checkpoint", "+".join(ckpts), "--seed", "9", "--random_masks",
+            "--prompt", "a photo of a cat wearing sunglasses+a photo of a dog+a photo of a beach", "--prompt_orig", "cat and dog",
+            "--concepts", "cat+dog+beach", "--modifier_token", "<new1>+<new2>+<new3>", "--negative_prompt", "blurry, low quality",
+            "--guidance_scale", "0.8", "--n_timesteps", "10", "--t_cond", "0.2", "--resampling_steps", "1", "--jumping_steps", "1",
+            "--resolution_h", "128", "--resolution_w", "128", "--output_path", str(tmp_path), "--output_path_all", str(tmp_path / "all")]
+    lat = fs.main(argv)
+    assert lat.shape == (1, 4, 16, 16) and torch.isfinite(lat).all()
+    from PIL import Image
+    im = np.array(Image.open(tmp_path / "all" / "cat and dog_9.png"))
+    assert im.shape == (128, 128, 3) and im.std() > 0
+    # the text half on its own, against the oracle on identical ids and injected rows
+    opt = fs.build_parser().parse_args(argv)
+    sts = [torch.load(p) for p in ckpts]
+    tp = T.TextPath(str(sdp))
+    te, ts_, K = tp.embed(opt, sts)
+    assert K == 3 and te[0].shape == (5, 77, 256) and te[1].shape == (5, 96) and ts_[0].shape == (3, 77, 256)
+    prompts, _single, _K = T.assemble_prompts(opt.prompt, opt.prompt_orig, opt.concepts, opt.modifier_token)
+    ids = [t([opt.negative_prompt] + prompts) for t in tp.tokenizers]
+    assert int(ids[0][2].max()) == 615 and int(ids[1][3].max()) == 616            # <new1>, <new2> got the appended ids
+    enc = []
+    for (sd, heads, act, eos), e in zip(towers.values(), tp.encoders):
+        sd = dict(sd)
+        key = [k for k in sd if k.endswith("token_embedding.weight")][0]
+        sd[key] = e.tok.float().cpu()                                                # table after injection
+        enc.append(({k: (v.to(torch.bfloat16).float() if v.dim() == 2 and "embedding" not in k else v) for k, v in sd.items()}, heads, act, eos))
+    want_e, want_p = CO.encode_prompt(enc, ids)
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(te[0], want_e) < 2e-2 and rel(te[1], want_p) < 3e-2

@@ -415,6 +415,13 @@ gemm_conv_kernel(const Params p) {
                             o[2] = fmaf(o[2], rs_row[i], b4.z); o[3] = fmaf(o[3], rs_row[i], b4.w); }
                 else if (p.ln_stats) { o[0] *= rs_row[i]; o[1] *= rs_row[i]; o[2] *= rs_row[i]; o[3] *= rs_row[i]; }
                 if (rg)   { const float4 b4 = *(const float4*)(rg + n);   o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+                if (p.epilogue == TMIX_EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r]);
+                } else if (p.epilogue == TMIX_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = o[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * o[r]));
+                }
                 if (Rb) {
                     uint2 rv;
                     if constexpr (PREF) rv = rres[i][j][g];
@@ -534,7 +541,8 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     if (d->bias && (((uintptr_t)d->bias) & 15)) TMIX_FAIL(TMIX_EALIGN, "gemm: bias must be 16-byte aligned");
     if (d->rowgroup_bias && (d->rows_per_group <= 0 || (((uintptr_t)d->rowgroup_bias) & 15))) TMIX_FAIL(TMIX_EINVAL, "gemm: rowgroup_bias needs rows_per_group > 0 and 16-byte alignment");
     if (d->epilogue == TMIX_EPI_GEGLU && ((d->N % 32) || has_trans || d->residual || d->rowgroup_bias)) TMIX_FAIL(TMIX_EINVAL, "gemm: GEGLU needs N %% 32 == 0 and no residual/transposed region");
-    if (d->epilogue != TMIX_EPI_NONE && d->epilogue != TMIX_EPI_GEGLU && d->epilogue != TMIX_EPI_F32OUT) TMIX_FAIL(TMIX_EINVAL, "gemm: bad epilogue %d", d->epilogue);
+    if (d->epilogue < TMIX_EPI_NONE || d->epilogue > TMIX_EPI_QUICKGELU) TMIX_FAIL(TMIX_EINVAL, "gemm: bad epilogue %d", d->epilogue);
+    if ((d->epilogue == TMIX_EPI_GELU || d->epilogue == TMIX_EPI_QUICKGELU) && (has_trans || d->residual)) TMIX_FAIL(TMIX_EINVAL, "gemm: activation epilogues take no residual/transposed region");
     if (d->epilogue == TMIX_EPI_F32OUT && (has_trans || (((uintptr_t)d->C) & 15))) TMIX_FAIL(TMIX_EINVAL, "gemm: fp32 output needs a 16-byte aligned C and no transposed region");
     if ((int64_t)d->M * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldw >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm: operand extent exceeds 32-bit element offsets");
     Params p = {};

@@ -184,16 +184,26 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------ row softmax (fp32 -> bf16)
-// one workgroup per row; the row (<= 64K columns) is streamed three times from L2/HBM (max, sum, write)
+// one workgroup per row; the row (<= 64K columns) is streamed three times from L2/HBM (max, sum, write).
+// seq > 0: causal rows of a [.., seq, cols] score stack -- row r attends to columns <= r % seq, the rest get P = 0.
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ S, int64_t ld_s, bf16_t* __restrict__ P,
-                                                           int64_t ld_p, int cols, float scale_log2e) {
+                                                           int64_t ld_p, int cols, float scale_log2e, int seq) {
     __shared__ float red[4];
     const float* row = S + (int64_t)blockIdx.x * ld_s;
     bf16_t* out = P + (int64_t)blockIdx.x * ld_p;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lim = seq > 0 ? (int)(blockIdx.x % (unsigned)seq) + 1 : cols;     // visible columns: [0, lim)
+    auto load = [&](int c) {
+        float4 v = *(const float4*)(row + c);
+        if (c + 0 >= lim) v.x = -INFINITY;
+        if (c + 1 >= lim) v.y = -INFINITY;
+        if (c + 2 >= lim) v.z = -INFINITY;
+        if (c + 3 >= lim) v.w = -INFINITY;
+        return v;
+    };
     float mx = -INFINITY;
     for (int c = tid * 4; c < cols; c += 1024) {
-        const float4 v = *(const float4*)(row + c);
+        const float4 v = load(c);
         mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }
 #pragma unroll
@@ -204,7 +214,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restri
     __syncthreads();
     float sum = 0.f;
     for (int c = tid * 4; c < cols; c += 1024) {
-        const float4 v = *(const float4*)(row + c);
+        const float4 v = load(c);
         sum += exp2f(v.x * scale_log2e - mx) + exp2f(v.y * scale_log2e - mx) + exp2f(v.z * scale_log2e - mx) + exp2f(v.w * scale_log2e - mx);
     }
 #pragma unroll
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restri
     __syncthreads();
     const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
     for (int c = tid * 4; c < cols; c += 1024) {
-        const float4 v = *(const float4*)(row + c);
+        const float4 v = load(c);
         uint2 o;
         o.x = pack_bf2(exp2f(v.x * scale_log2e - mx) * inv, exp2f(v.y * scale_log2e - mx) * inv);
         o.y = pack_bf2(exp2f(v.z * scale_log2e - mx) * inv, exp2f(v.w * scale_log2e - mx) * inv);
@@ -458,7 +468,18 @@ extern "C" int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t 
     if (!S || !P) TMIX_FAIL(TMIX_EINVAL, "softmax_rows: null pointer");
     if (rows <= 0 || cols <= 0 || (cols % 4) || (ld_s % 4) || (ld_p % 4)) TMIX_FAIL(TMIX_ESHAPE, "softmax_rows: rows=%lld cols=%d (cols, ld %% 4 == 0)", (long long)rows, cols);
     if (!aligned16(S) || (((uintptr_t)P) & 7)) TMIX_FAIL(TMIX_EALIGN, "softmax_rows: pointer alignment");
-    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f);
+    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, 0);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_softmax_rows_causal(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale,
+                                        int seq, void* stream) {
+    if (!S || !P) TMIX_FAIL(TMIX_EINVAL, "softmax_rows_causal: null pointer");
+    if (rows <= 0 || cols <= 0 || seq <= 0 || seq > cols || (rows % seq) || (cols % 4) || (ld_s % 4) || (ld_p % 4))
+        TMIX_FAIL(TMIX_ESHAPE, "softmax_rows_causal: rows=%lld cols=%d seq=%d (rows %% seq == 0, seq <= cols, cols/ld %% 4 == 0)", (long long)rows, cols, seq);
+    if (!aligned16(S) || (((uintptr_t)P) & 7)) TMIX_FAIL(TMIX_EALIGN, "softmax_rows_causal: pointer alignment");
+    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, seq);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }

@@ -70,7 +70,7 @@ def stats_parts(N, tile_cfg):
 
 def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows_per_group=0, geglu=False,
                    out_t=None, n_trans_begin=-1, tile_cfg=0, row_stats_out=None, ln_stats=None, ln_colsum=None,
-                   ln_eps=1e-5, ln_parts=0):
+                   ln_eps=1e-5, ln_parts=0, act=None, out_f32=None):
     """a [batch?,M,K] bf16 (last dim contiguous), w [batch?,N,K] bf16, out [batch?,M,N'] bf16."""
     a3 = a if a.dim() == 3 else a.unsqueeze(0)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -103,7 +103,11 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
         d.Ct, d.ldct, d.strideCt = t3.data_ptr(), t3.stride(1), (t3.stride(0) if batch > 1 else 0)
         d.n_trans_begin = n_trans_begin
     d.M, d.N, d.K, d.batch = M, N, K, batch
-    d.epilogue = L.EPI_GEGLU if geglu else L.EPI_NONE
+    d.epilogue = L.EPI_GEGLU if geglu else {None: L.EPI_NONE, "gelu": L.EPI_GELU, "quick_gelu": L.EPI_QUICKGELU}[act]
+    if out_f32 is not None:                # fp32 C (attention scores): [batch?, M, ld >= N]
+        f3 = out_f32 if out_f32.dim() == 3 else out_f32.unsqueeze(0)
+        assert f3.dtype == torch.float32 and f3.stride(2) == 1 and out is None and act is None and not geglu
+        d.C, d.ldc, d.strideC, d.epilogue = f3.data_ptr(), f3.stride(1), (f3.stride(0) if batch > 1 else 0), L.EPI_F32OUT
     d.tile_cfg = tile_cfg
     if row_stats_out is not None:          # fp32 [parts, rows, 2] per-column-tile partial sums, rows = batch*M
         st = row_stats_out
@@ -126,7 +130,7 @@ def gemm(a, w, out=None, **kw):
     """out = epi(a @ w^T).  Allocates out ([.., M, N] or [.., M, N/2] for GEGLU) when not given."""
     _need_cuda(a, w)
     lib = L.load()
-    if out is None and not (kw.get("out_t") is not None and kw.get("n_trans_begin", -1) == 0):
+    if out is None and kw.get("out_f32") is None and not (kw.get("out_t") is not None and kw.get("n_trans_begin", -1) == 0):
         N = w.shape[-2]
         No = N // 2 if kw.get("geglu") else N
         if kw.get("out_t") is not None:
@@ -134,7 +138,7 @@ def gemm(a, w, out=None, **kw):
         out = torch.empty(*a.shape[:-1], No, device=a.device, dtype=BF16)
     d = make_gemm_desc(a, w, out, **kw)
     L.check(lib.tmix_gemm_bf16(C.byref(d), _stream()), "tmix_gemm_bf16")
-    return out
+    return out if out is not None else kw.get("out_f32")
 
 
 def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0):
@@ -275,3 +279,13 @@ def linear_small(x, w, bias=None, add=None, act_in=False, act_out=False, out=Non
     L.check(lib.tmix_linear_small(_p(x), _p(w), _p(bias), _p(add), _p(out), M, N, K, int(bool(act_in)),
                                   int(bool(act_out)), _stream()), "tmix_linear_small")
     return out
+
+
+def softmax_rows_causal(scores, probs, seq, scale):
+    """probs[r, :] = softmax(scale * scores[r, :c<=r%seq]) (bf16), zeros elsewhere; scores fp32 [rows, cols]."""
+    _need_cuda(scores, probs)
+    rows, cols = scores.shape
+    assert scores.dtype == torch.float32 and probs.dtype == BF16 and probs.shape == scores.shape
+    L.check(L.load().tmix_softmax_rows_causal(_p(scores), scores.stride(0), _p(probs), probs.stride(0), rows, cols, float(scale),
+                                              int(seq), _stream()), "tmix_softmax_rows_causal")
+    return probs

@@ -55,6 +55,28 @@ class UNetConfig:
         return self.pooled_dim + 6 * self.addition_time_embed_dim
 
 
+    @classmethod
+    def from_diffusers(cls, cfg: dict):
+        """UNet2DConditionModel config.json of a diffusers-layout SDXL checkpoint.  `attention_head_dim` there holds the
+        HEAD COUNT per level (a diffusers naming quirk): SDXL's [5,10,20] over (320,640,1280) channels = 64 per head."""
+        ch = tuple(cfg["block_out_channels"])
+        tl = cfg.get("transformer_layers_per_block", 1)
+        tl = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * len(ch)
+        down = cfg.get("down_block_types", ["CrossAttnDownBlock2D"] * len(ch))
+        tl = tuple(n if "CrossAttn" in t else 0 for n, t in zip(tl, down))
+        heads = cfg.get("attention_head_dim", 8)
+        heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * len(ch)
+        hd = {c // h for c, h, n in zip(ch, heads, tl) if n}
+        if hd != {64}:
+            raise ValueError(f"attention head size {sorted(hd)}: the attention kernel is built for 64 (SDXL)")
+        add = cfg.get("addition_time_embed_dim", 256)
+        return cls(in_channels=cfg.get("in_channels", 4), out_channels=cfg.get("out_channels", 4), block_out_channels=ch,
+                   layers_per_block=cfg.get("layers_per_block", 2), transformer_layers=tl, head_dim=64,
+                   cross_dim=cfg.get("cross_attention_dim", 2048),
+                   pooled_dim=cfg.get("projection_class_embeddings_input_dim", 2816) - 6 * add,
+                   addition_time_embed_dim=add, norm_groups=cfg.get("norm_num_groups", 32))
+
+
 SDXL = UNetConfig()
 TINY = UNetConfig(block_out_channels=(64, 128, 256), transformer_layers=(0, 1, 2), cross_dim=128,
                   pooled_dim=64, addition_time_embed_dim=32)

@@ -169,3 +169,26 @@ def synthetic_concepts(cfg, kind, K, device="cpu", dtype=torch.float32):
             raise ValueError(kind)
         out.append(sd)
     return out
+
+
+def synthetic_clip_state_dict(d: int, layers: int, inter: int, vocab: int = 49408, max_pos: int = 77, proj: int | None = None,
+                              seed: int = 77, dtype=torch.float32):
+    """random-init text tower in transformers' CLIPTextModel key scheme (no checkpoints exist offline):
+    Linear weights N(0, 1/fan_in), embeddings N(0, 0.02), norms gamma 1 + small noise / beta small noise."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std=1.0: (torch.randn(*s, generator=g) * std).to(dtype)
+    sd = {"text_model.embeddings.token_embedding.weight": rn(vocab, d, std=0.02),
+          "text_model.embeddings.position_embedding.weight": rn(max_pos, d, std=0.01)}
+    for i in range(layers):
+        p = f"text_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{n}.weight"] = rn(d, d, std=d ** -0.5)
+            sd[p + f"self_attn.{n}.bias"] = rn(d, std=0.02)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = rn(inter, d, std=d ** -0.5), rn(inter, std=0.02)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = rn(d, inter, std=inter ** -0.5), rn(d, std=0.02)
+        for n in ("layer_norm1", "layer_norm2"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    sd["text_model.final_layer_norm.weight"], sd["text_model.final_layer_norm.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    if proj:
+        sd["text_projection.weight"] = rn(proj, d, std=d ** -0.5)
+    return sd
