@@ -58,6 +58,17 @@ int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, cons
                             float g, float sa, float s1, float sa_next, float s1_next, int is_last,
                             void* stream);
 
+/* Video sampler (I2VGen-XL loop, BASELINE config #5; replaces video_gen/pipeline_i2vgen_xl.py:699-719):
+ *   x [n], v [2n] (uncond rows first), out [n], all of `dtype` (TMIX_F32 / TMIX_F16 / TMIX_BF16); sa = sqrt(alpha(t)) etc. with
+ *   the UN-shifted table of that pipeline (:480-482).  v' = v_u + g (v_t - v_u); eps = sa v' + s1 x; x0 = sa x - s1 v';
+ *   out = sa_next x0 + s1_next eps.  TMIX_F16 rounds after every binary op like the reference's fp16 tensors. */
+int tmix_vpred_step(const void* x, const void* v, void* out, int dtype, int64_t n, float g,
+                    float sa, float s1, float sa_next, float s1_next, void* stream);
+/* First-frame feature injection of the patched ResnetBlock2D.forward (video_gen/utils_attn.py:433-455), in place on
+ * x [clips][frames][per_frame]: frames 1.. <- frame 0 (hard) or interp*frame0 + one_minus_interp*frame. */
+int tmix_frame_inject(void* x, int dtype, int clips, int frames, int64_t per_frame, int hard, float interp,
+                      float one_minus_interp, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogues:  C[b] = epi(A[b] (MxK) * W[b]^T (NxK)).
  * Replaces the Linear layers inside the UNet call at fusion_sampling.py:340/374/406/414/440

@@ -268,6 +268,40 @@ class TweedieOracle:
 
 
 # --------------------------------------------------------------- attention hooks
+# ------------------------------------------------------- video sampler (config #5) step arithmetic
+def video_alpha(alphas_cumprod, final_alpha_cumprod, t):
+    """video_gen/pipeline_i2vgen_xl.py:480-482: the UN-shifted table (alpha(t) = acp[t]), final_alpha_cumprod below 0."""
+    return F32(alphas_cumprod[int(t)]) if t >= 0 else F32(final_alpha_cumprod)
+
+
+def video_vpred_step(x, v, g, at, at_next, lowp=None):
+    """pipeline_i2vgen_xl.py:699-719: CFG on the v-prediction, eps = sqrt(at) v + sqrt(1-at) x,
+    x0 = sqrt(at) x - sqrt(1-at) v, x' = sqrt(at') x0 + sqrt(1-at') eps.  x [B,...], v [2B,...] (uncond rows first).
+    Latents and predictions share the model dtype there, so with lowp every binary op rounds to it."""
+    B = x.shape[0]
+    vu, vt = v[:B], v[B:]
+    vv = _h(vu + _h(F32(g) * _h(vt - vu, lowp), lowp), lowp)
+    sa, s1 = np.sqrt(F32(at)).astype(F32), np.sqrt(F32(1) - F32(at)).astype(F32)
+    san, s1n = np.sqrt(F32(at_next)).astype(F32), np.sqrt(F32(1) - F32(at_next)).astype(F32)
+    eps = _h(_h(_s(sa, lowp) * vv, lowp) + _h(_s(s1, lowp) * x, lowp), lowp)
+    x0 = _h(_h(_s(sa, lowp) * x, lowp) - _h(_s(s1, lowp) * vv, lowp), lowp)
+    return _h(_h(_s(san, lowp) * x0, lowp) + _h(_s(s1n, lowp) * eps, lowp), lowp)
+
+
+def inject_first_frame(x, batch, frames, interp=None, lowp=None):
+    """video_gen/utils_attn.py:433-455 on a [(b t), ...] tensor: frames 1.. of every clip become the clip's first frame
+    (interp None: hard copy, mid_block resnets) or interp*first + (1-interp)*frame (up_blocks[1].resnets[0])."""
+    y = x.reshape(batch, frames, *x.shape[1:]).copy()
+    first = y[:, :1]
+    if interp is None:
+        y[:, 1:] = first
+    else:
+        # interp is a Python float there: a wrapped number multiplies in fp32 on every device (1-interp formed in double)
+        a, b = _h(F32(interp) * np.broadcast_to(first, y[:, 1:].shape), lowp), _h(F32(1.0 - float(interp)) * y[:, 1:], lowp)
+        y[:, 1:] = _h(a + b, lowp)
+    return y.reshape(x.shape)
+
+
 def _heads(t, h):
     b, s, c = t.shape
     return t.reshape(b, s, h, c // h).transpose(0, 2, 1, 3)

@@ -158,3 +158,33 @@ def test_clip_oracle_matches_transformers_vectors(name, golden_dir):
     torch.testing.assert_close(pooled, torch.from_numpy(z[name + ".pooled"]), rtol=1e-4, atol=2e-5)
     if name == "g":          # legacy eos_token_id == 2: the pooled row sits at the largest id (the added token), not at EOS
         assert int(ids[1].argmax()) == 3 and int(ids[2].argmax()) == 7
+
+
+def test_video_step_and_injection_match_reference_vectors(golden_dir):
+    """oracle video_vpred_step / inject_first_frame against tests/golden/video_step.npz, produced by executing the
+    reference's statements (oracle/gen_golden_video.py): fp32 to 1e-6, fp16 bit-exact with torch-CPU scalar semantics."""
+    z = np.load(os.path.join(golden_dir, "video_step.npz"))
+    acp = z["alphas_cumprod"]
+    for dt, lowp in (("f32", None), ("f16", np.float16)):
+        O.CPU_SCALAR_TENSOR_SEMANTICS = lowp is not None
+        try:
+            for case in range(4):
+                k = f"step.{dt}.{case}"
+                t, skip, g = z[k + ".meta"]
+                at, atn = O.video_alpha(acp, acp[0], int(t)), O.video_alpha(acp, acp[0], int(t) - int(skip))
+                got = O.video_vpred_step(z[k + ".x"], z[k + ".v"], g, at, atn, lowp)
+                if lowp is None:
+                    np.testing.assert_allclose(got, z[k + ".out"], rtol=0, atol=2e-6)
+                else:
+                    assert np.array_equal(got, z[k + ".out"]), (k, np.abs(got - z[k + ".out"]).max())
+            for case in range(5):
+                k = f"inject.{dt}.{case}"
+                hard, soft, interp, _t, active = z[k + ".meta"]
+                x = z[k + ".x"]
+                got = O.inject_first_frame(x, 2, 16, None if hard else float(interp), lowp) if active else x
+                if lowp is None:
+                    np.testing.assert_allclose(got, z[k + ".out"], rtol=0, atol=1e-6)
+                else:
+                    assert np.array_equal(got, z[k + ".out"]), k
+        finally:
+            O.CPU_SCALAR_TENSOR_SEMANTICS = False

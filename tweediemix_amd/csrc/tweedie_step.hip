@@ -83,7 +83,90 @@ int launch(const float* x, const void* eps, const float* masks, float* out_x, fl
     return TMIX_OK;
 }
 
+// ------------------------------------------------------------------ video sampler (I2VGen-XL loop, config #5)
+template <int DT> struct StT;
+template <> struct StT<TMIX_F32>  { static __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; } };
+template <> struct StT<TMIX_F16>  { static __device__ __forceinline__ void st(__half* p, int64_t i, float v) { p[i] = __float2half_rn(v); } };
+template <> struct StT<TMIX_BF16> { static __device__ __forceinline__ void st(bf16_t* p, int64_t i, float v) { p[i] = f2bf(v); } };
+
+// video_gen/pipeline_i2vgen_xl.py:699-719 in one pass: CFG on the v-prediction, eps / x0 from (x, v), DDIM move.
+// Latents and predictions share the model dtype in that loop, so in fp16 mode EVERY binary op rounds (rnd<DT>).
+template <int DT>
+__global__ void __launch_bounds__(256)
+vpred_step_kernel(const typename EpsT<DT>::T* __restrict__ x, const typename EpsT<DT>::T* __restrict__ v,
+                  typename EpsT<DT>::T* __restrict__ out, int64_t n, float g, float sa, float s1, float sa_n, float s1_n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float xv = EpsT<DT>::ld(x, i);
+        const float vv = cfg<DT>(EpsT<DT>::ld(v, i), EpsT<DT>::ld(v, n + i), g);
+        const float eps = rnd<DT>(rnd<DT>(sa * vv) + rnd<DT>(s1 * xv));
+        const float x0 = rnd<DT>(rnd<DT>(sa * xv) - rnd<DT>(s1 * vv));
+        StT<DT>::st(out, i, rnd<DT>(rnd<DT>(sa_n * x0) + rnd<DT>(s1_n * eps)));
+    }
+}
+
+// video_gen/utils_attn.py:433-455: frames 1.. of every clip <- first frame (hard) or interp*first + (1-interp)*frame
+template <int DT>
+__global__ void __launch_bounds__(256)
+frame_inject_kernel(typename EpsT<DT>::T* __restrict__ x, int64_t per_frame, int frames, int64_t n, int hard, float a, float b) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t per_clip = (int64_t)(frames - 1) * per_frame;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t clip = i / per_clip, r = i - clip * per_clip;
+        const int64_t e = r % per_frame, base = clip * frames * per_frame;
+        const float first = EpsT<DT>::ld(x, base + e);
+        const int64_t dst = base + per_frame + r;
+        const float o = hard ? first : rnd<DT>(rnd<DT>(a * first) + rnd<DT>(b * EpsT<DT>::ld(x, dst)));
+        StT<DT>::st(x, dst, o);
+    }
+}
+
+template <int DT>
+int launch_vpred(const void* x, const void* v, void* out, int64_t n, float g, float sa, float s1, float sa_n, float s1_n, hipStream_t st) {
+    typedef typename EpsT<DT>::T T;
+    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    vpred_step_kernel<DT><<<blocks, 256, 0, st>>>((const T*)x, (const T*)v, (T*)out, n, g, sa, s1, sa_n, s1_n);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+template <int DT>
+int launch_inject(void* x, int64_t per_frame, int frames, int64_t n, int hard, float a, float b, hipStream_t st) {
+    typedef typename EpsT<DT>::T T;
+    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    frame_inject_kernel<DT><<<blocks, 256, 0, st>>>((T*)x, per_frame, frames, n, hard, a, b);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
 }  // namespace
+
+extern "C" int tmix_vpred_step(const void* x, const void* v, void* out, int dtype, int64_t n, float g,
+                               float sa, float s1, float sa_next, float s1_next, void* stream) {
+    if (!x || !v || !out) TMIX_FAIL(TMIX_EINVAL, "vpred_step: null pointer");
+    if (n < 1) TMIX_FAIL(TMIX_ESHAPE, "vpred_step: empty latent");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case TMIX_F32:  return launch_vpred<TMIX_F32>(x, v, out, n, g, sa, s1, sa_next, s1_next, st);
+    case TMIX_F16:  return launch_vpred<TMIX_F16>(x, v, out, n, g, sa, s1, sa_next, s1_next, st);
+    case TMIX_BF16: return launch_vpred<TMIX_BF16>(x, v, out, n, g, sa, s1, sa_next, s1_next, st);
+    }
+    TMIX_FAIL(TMIX_EINVAL, "vpred_step: bad dtype %d", dtype);
+}
+
+extern "C" int tmix_frame_inject(void* x, int dtype, int clips, int frames, int64_t per_frame, int hard, float interp,
+                                 float one_minus_interp, void* stream) {
+    if (!x) TMIX_FAIL(TMIX_EINVAL, "frame_inject: null pointer");
+    if (clips < 1 || frames < 2 || per_frame < 1) TMIX_FAIL(TMIX_ESHAPE, "frame_inject: clips=%d frames=%d per_frame=%lld", clips, frames, (long long)per_frame);
+    const int64_t n = (int64_t)clips * (frames - 1) * per_frame;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case TMIX_F32:  return launch_inject<TMIX_F32>(x, per_frame, frames, n, hard, interp, one_minus_interp, st);
+    case TMIX_F16:  return launch_inject<TMIX_F16>(x, per_frame, frames, n, hard, interp, one_minus_interp, st);
+    case TMIX_BF16: return launch_inject<TMIX_BF16>(x, per_frame, frames, n, hard, interp, one_minus_interp, st);
+    }
+    TMIX_FAIL(TMIX_EINVAL, "frame_inject: bad dtype %d", dtype);
+}
 
 extern "C" int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, const float* masks,
                                        float* out_x, float* out_x0, int K, int channels, int64_t hw, int mode,

@@ -66,6 +66,8 @@ SIGNATURES = {
                                       C.c_int, vp]),
     "tmix_layernorm": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, f32, vp]),
     "tmix_zero": (C.c_int, [vp, i64, vp]),
+    "tmix_vpred_step": (C.c_int, [vp, vp, vp, C.c_int, i64, f32, f32, f32, f32, f32, vp]),
+    "tmix_frame_inject": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, C.c_int, f32, f32, vp]),
     "tmix_gemm_tile_shape": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tmix_gemm_stats_parts": (C.c_int, [C.c_int, C.c_int]),
     "tmix_concat_channels": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, i64, vp]),

@@ -289,3 +289,29 @@ def softmax_rows_causal(scores, probs, seq, scale):
     L.check(L.load().tmix_softmax_rows_causal(_p(scores), scores.stride(0), _p(probs), probs.stride(0), rows, cols, float(scale),
                                               int(seq), _stream()), "tmix_softmax_rows_causal")
     return probs
+
+
+def vpred_step(x, v, g, at, at_next, out=None):
+    """I2VGen-XL loop update (video_gen/pipeline_i2vgen_xl.py:699-719): x [B,...], v [2B,...] (uncond rows first) of one
+    dtype; at / at_next from the un-shifted alpha table.  Returns the next latents (same dtype)."""
+    _need_cuda(x, v)
+    assert x.is_contiguous() and v.is_contiguous() and v.numel() == 2 * x.numel() and v.dtype == x.dtype
+    out = torch.empty_like(x) if out is None else out
+    f = np.float32
+    sa, s1 = np.sqrt(f(at)), np.sqrt(f(1) - f(at))
+    san, s1n = np.sqrt(f(at_next)), np.sqrt(f(1) - f(at_next))
+    L.check(L.load().tmix_vpred_step(_p(x), _p(v), _p(out), _EPS_DT[x.dtype], x.numel(), float(g), float(sa), float(s1),
+                                     float(san), float(s1n), _stream()), "tmix_vpred_step")
+    return out
+
+
+def frame_inject(x, clips, frames, interp=None):
+    """first-frame feature injection (video_gen/utils_attn.py:433-455), in place on x [(clips*frames), ...] contiguous."""
+    _need_cuda(x)
+    assert x.is_contiguous() and x.shape[0] == clips * frames
+    per = x.numel() // (clips * frames)
+    hard = interp is None
+    a = 0.0 if hard else float(np.float32(interp))
+    b = 0.0 if hard else float(np.float32(1.0 - float(interp)))
+    L.check(L.load().tmix_frame_inject(_p(x), _EPS_DT[x.dtype], clips, frames, per, int(hard), a, b, _stream()), "tmix_frame_inject")
+    return x

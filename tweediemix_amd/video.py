@@ -1,0 +1,71 @@
+"""Host side of the video sampler's per-step path (BASELINE config #5): the denoising loop of
+video_gen/pipeline_i2vgen_xl.py:647-719 and the feature-injection schedule of video_gen/utils_attn.py:14-23,389-474, over
+the HIP kernels `tmix_vpred_step` and `tmix_frame_inject`.  The I2VGen-XL UNet itself (diffusers `I2VGenXLUNet`, not in
+/root/reference) is NOT rebuilt in this round: the loop takes the network as a callable, so the reference's own module (or
+a later native one) plugs in; everything the reference does around that call is here.
+
+Quirks kept: alpha(t) indexes the UN-shifted alphas_cumprod (unlike the image sampler) and falls back to
+final_alpha_cumprod below 0 (:480-482); skip = 1000 // n (:647); the injection schedule is the first int(n * ratio)
+timesteps, also active when t == 1000 (utils_attn.py:433,444); clips are hard-wired to b=2, t=16 there (:439,449)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class VideoSchedule:
+    """alphas_cumprod [1000] (from the checkpoint's scheduler), leading timesteps with steps_offset (diffusers DDIMScheduler
+    set_timesteps as configured for i2vgen-xl), skip = 1000 // n."""
+
+    def __init__(self, alphas_cumprod, n_steps: int, steps_offset: int = 1, set_alpha_to_one: bool = False):
+        self.acp = np.asarray(alphas_cumprod, np.float32)
+        self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.acp[0]
+        self.n = n_steps
+        self.skip = len(self.acp) // n_steps
+        self.timesteps = (np.arange(0, n_steps) * self.skip).round()[::-1].astype(np.int64) + steps_offset
+
+    def alpha(self, t: int):
+        return self.acp[int(t)] if t >= 0 else self.final_alpha_cumprod
+
+    def injection_schedule(self, ratio: float):
+        k = int(self.n * ratio)
+        return set(int(t) for t in self.timesteps[:k]) if k >= 0 else set()
+
+
+def injection_active(t: int, schedule) -> bool:
+    return schedule is not None and (int(t) in schedule or int(t) == 1000)
+
+
+class FeatureInjector:
+    """what `register_conv_control_efficient` + `register_time` do to mid_block.resnets[0,1] (hard copy of the first
+    frame's features) and up_blocks[1].resnets[0] (interp blend): call `apply(site, features)` on the resnet OUTPUT
+    [(2*16), ...] of those three modules (e.g. from a forward hook)."""
+
+    SITES = {"mid_block.resnets.0": "hard", "mid_block.resnets.1": "hard", "up_blocks.1.resnets.0": "interp"}
+
+    def __init__(self, schedule, interp: float, clips: int = 2, frames: int = 16):
+        self.schedule, self.interp, self.clips, self.frames = schedule, interp, clips, frames
+        self.t = None
+
+    def register_time(self, t: int):
+        self.t = int(t)
+
+    def apply(self, site: str, features: torch.Tensor) -> torch.Tensor:
+        if injection_active(self.t, self.schedule):
+            ops.frame_inject(features, self.clips, self.frames, None if self.SITES[site] == "hard" else self.interp)
+        return features
+
+
+@torch.no_grad()
+def sample_loop(unet, latents: torch.Tensor, schedule: VideoSchedule, guidance_scale: float, injector: FeatureInjector | None = None):
+    """pipeline_i2vgen_xl.py:680-719.  unet(latent_model_input [2B,C,F,H,W], t) -> v-prediction of the same shape (the
+    caller closes over prompt/image conditioning); latents [B,C,F,H,W] on the GPU in the model dtype."""
+    x = latents.contiguous()
+    for t in schedule.timesteps:
+        if injector is not None:
+            injector.register_time(t)
+        v = unet(torch.cat([x, x]), int(t)).contiguous()
+        x = ops.vpred_step(x, v, guidance_scale, schedule.alpha(int(t)), schedule.alpha(int(t) - schedule.skip))
+    return x
