@@ -117,10 +117,17 @@ def gemm_roofline(plan):
         for k, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"  {str(k):60s} n={n:4d} total={ms:7.3f}ms avg={1e3 * ms / n:7.1f}us {fl / ms / 1e9:6.0f}TF", file=sys.stderr)
     out = {}
+    # algorithmic HBM bytes of a GEMM launch: A and W read once, C written once, residual read once (bf16), GEGLU halves C
+    gb = 0
+    for d, _f in plan.launches["gemm"]:
+        n_out = d.N // 2 if d.epilogue == L.EPI_GEGLU else d.N
+        wsets = d.batch if d.strideW else 1
+        gb += 2 * (d.batch * d.M * d.K + wsets * d.N * d.K + d.batch * d.M * n_out + (d.batch * d.M * d.N if d.residual else 0))
     for key in ev:
         ms = [a.elapsed_time(b) for a, b in ev[key]]
         out[key] = dict(launches=len(ms), total_ms=float(sum(ms)), avg_us=float(1e3 * sum(ms) / max(1, len(ms))),
                         tflops=float(sum(fl_by[key]) / max(1e-9, sum(ms)) / 1e9), flops=float(sum(fl_by[key])))
+    out["gemm"]["alg_bytes_per_launch"] = gb / max(1, len(plan.launches["gemm"]))
     return out
 
 
@@ -298,7 +305,7 @@ def main():
             "achieved_tflops_whole_step": plan.flops / 1e12 / (dt / args.steps),
             "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<0> (tmix_gemm_bf16)", "achieved": g["tflops"],
                          "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(), "launches_per_step": g["launches"], "avg_launch_us": g["avg_us"],
+                         "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": g["alg_bytes_per_launch"], "launches_per_step": g["launches"], "avg_launch_us": g["avg_us"],
                          "flops_per_step": g["flops"], "concurrent_replay": gemm_concurrent(plan),
                          "other_kernels": {k: {kk: v[kk] for kk in ("launches", "total_ms", "avg_us", "tflops")}
                                            for k, v in roof.items() if k != "gemm"}},
