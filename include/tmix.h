@@ -83,7 +83,9 @@ enum { TMIX_EPI_NONE = 0, TMIX_EPI_GEGLU = 1, TMIX_EPI_F32OUT = 2 /* C is fp32 [
 /* workgroup tilings of the MFMA mainloop (BM x BN, waves, LDS ring depth); AUTO = built-in heuristic */
 enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, TMIX_TILE_128x128_S4 = 3,
        TMIX_TILE_256x256_S2 = 4, TMIX_TILE_256x128_W4 = 5, TMIX_TILE_256x256_W4 = 6, TMIX_TILE_128x160_S2 = 7,
-       TMIX_TILE_COUNT = 7 };
+       /* the same tilings with one extra LOADER wave that issues every LDS-DMA (the math waves only read LDS and issue MFMAs) */
+       TMIX_TILE_128x160_S2_LW = 8, TMIX_TILE_256x128_S3_LW = 9, TMIX_TILE_128x128_S2_LW = 10, TMIX_TILE_256x256_S2_LW = 11,
+       TMIX_TILE_COUNT = 11 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

@@ -55,14 +55,23 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
+// LW = 1 adds a LOADER wave to the WM x WN math waves (wave specialisation): measured on this chip (tools/ubench/dma_issue),
+// an LDS-DMA instruction blocks the issuing wave for ~100 cycles and a wave's own MFMAs queue up behind its DMA issue
+// (8 DMA + 32 MFMA per wave: 0.96 us per round), whereas DMA issued by one wave overlaps the MFMAs of OTHER waves almost
+// perfectly (the same work split as 1 loader + 4 math waves: 0.53 us).  So with LW the math waves never touch VMEM in the
+// K loop: the loader streams every K-tile (all (BM+BN)/8 instructions), waits for it with a counted vmcnt, and the
+// per-iteration s_barrier hands it over.
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0>
+// (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
+// waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
+__global__ void __launch_bounds__((WM * WN + LW) * 64, LW ? 3 : (WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
 gemm_conv_kernel(const Params p) {
-    constexpr int NW = WM * WN;
+    constexpr int NW = WM * WN;                        // math waves
     constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
     constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
     constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
-    constexpr int RA = BM / 8 / NW, RB = BN / 8 / NW;  // LDS-DMA instructions per wave per stage
+    constexpr int SW = LW ? 1 : NW;                    // waves that share the staging of a K-tile
+    constexpr int RA = BM / 8 / SW, RB = BN / 8 / SW;  // LDS-DMA instructions per staging wave per stage
     constexpr int L = RA + RB;
     static_assert(RA >= 1 && RB >= 1 && FM >= 1 && FN >= 1, "tile/wave geometry");
     static_assert((NS - 2) * L <= 63, "vmcnt immediate");
@@ -72,6 +81,9 @@ gemm_conv_kernel(const Params p) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w / WN, wc = w - wr * WN;
+    const bool loader = LW && (w == NW);               // wave-uniform role
+    const bool stager = LW ? loader : true;
+    const int sw_id = LW ? 0 : w;                      // this wave's slot among the staging waves
 
     // Tile order: each XCD (private 4 MiB L2) owns a contiguous range of logical ids, and ids sweep GM tile-rows
     // per tile-column, so the ~64 tiles resident on an XCD at any time form a compact GM x (64/GM) patch that
@@ -94,18 +106,45 @@ gemm_conv_kernel(const Params p) {
     // ---- per-lane staging sources. Wave-instruction idx = r*NW + w covers LDS rows idx*8 .. idx*8+7.
     const int lrow = lane >> 3;
     // per-lane offsets are 32-bit element counts off wave-uniform bases (saddr + voffset form of global_load_lds)
-    unsigned woff[RB], aoff[RA];
-    int pb[RA], py[RA], px[RA], asw[RA];
+    // A loader wave (LW) covers ALL rows of the tile; its per-lane offsets follow from two parity variants (the swizzle
+    // of instruction idx depends on idx & 1 only) plus a wave-uniform row advance, clamped like the per-wave arrays below.
+    constexpr int RAa = (LW && !CONV) ? 1 : RA, RBa = LW ? 1 : RB;
+    unsigned woff[RBa], aoff[RAa];
+    int pb[CONV ? RA : 1], py[CONV ? RA : 1], px[CONV ? RA : 1], asw[(CONV && !LW) ? RA : 1];
+    unsigned aoffp[2], amaxp[2], woffp[2], wmaxp[2], swp[2];
+    if constexpr (LW) {
+        if (loader) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const unsigned sw = ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 8;
+                swp[par] = sw;
+                woffp[par] = ((unsigned)(n0 + par * 8 + lrow) * (unsigned)p.ldw + sw) * 2u;
+                wmaxp[par] = ((unsigned)(p.N - 1) * (unsigned)p.ldw + sw) * 2u;
+                aoffp[par] = ((unsigned)(m0 + par * 8 + lrow) * (unsigned)p.lda + sw) * 2u;
+                amaxp[par] = ((unsigned)(p.M - 1) * (unsigned)p.lda + sw) * 2u;
+            }
+            if constexpr (CONV) {
+                const int hw = p.Ho * p.Wo;
+#pragma unroll
+                for (int r = 0; r < RA; ++r) {
+                    int m = m0 + r * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+                    pb[r] = m / hw; const int rem = m - pb[r] * hw;
+                    py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
+                }
+            }
+        }
+    } else
+    if (stager) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        const int idx = r * NW + w;
+        const int idx = r * SW + sw_id;
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
         int n = n0 + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
         woff[r] = ((unsigned)n * (unsigned)p.ldw + sw) * 2u;
     }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-        const int idx = r * NW + w;
+        const int idx = r * SW + sw_id;
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;
         int m = m0 + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
         asw[r] = sw;
@@ -117,6 +156,7 @@ gemm_conv_kernel(const Params p) {
         } else {
             aoff[r] = ((unsigned)m * (unsigned)p.lda + sw) * 2u;
         }
+    }
     }
 
     const int nk = p.K / BK;
@@ -135,23 +175,51 @@ gemm_conv_kernel(const Params p) {
             else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
             else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
                    ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
-            cvo[r] = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + asw[r]) * 2u : 0x80000000u;
+            const unsigned sw = LW ? swp[r & 1] : (unsigned)asw[LW ? 0 : r];
+            cvo[r] = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + sw) * 2u : 0x80000000u;
         }
     };
-    if constexpr (CONV) conv_tap_offsets();
+    if constexpr (CONV) { if (stager) conv_tap_offsets(); }
 
     auto stage = [&](int buf, int kt) {
         char* sA = smem + buf * STAGE;
         char* sW = sA + A_TILE;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + (r * NW + w) * 1024);
-            else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + (r * NW + w) * 1024);
+            if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + (r * SW + sw_id) * 1024);
+            else if constexpr (LW) blds16(rsA, min(aoffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.lda), amaxp[r & 1]),
+                                          (unsigned)kt * (BK * 2), sA + r * 1024);
+            else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + (r * SW + sw_id) * 1024);
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + (r * NW + w) * 1024);
+        for (int r = 0; r < RB; ++r) {
+            if constexpr (LW) blds16(rsW, min(woffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.ldw), wmaxp[r & 1]),
+                                     (unsigned)kt * (BK * 2), sW + r * 1024);
+            else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + (r * SW + sw_id) * 1024);
+        }
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < 9) conv_tap_offsets(); } }
     };
+
+    // ---- loader wave (LW): leaves here, before any math-wave state (accumulators, fragments) becomes live
+    if constexpr (LW) {
+        if (loader) {                                  // ---- loader wave: DMA issue + counted waits only
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) stage(s, s);
+            if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            int nxt = NS - 1;
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool more = kt + NS - 1 < nk;
+                if (more) stage(nxt, kt + NS - 1);    // its ring slot was released by the barrier that ended iteration kt-1
+                if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            }
+            if (p.stats_out) __syncthreads();          // the math waves' statistics reduction has one more barrier
+            return;
+        }
+    }
 
     // ---- fused LayerNorm (consumer side), part 1: the producer GEMM left ln_parts partial {sum, sum of squares}
     // per row (one per column tile of ITS grid).  Thread t owns tile row t and tile column t: the partials (added in
@@ -249,14 +317,6 @@ gemm_conv_kernel(const Params p) {
         }
     };
 
-    // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) stage(s, s);
-    ln_reduce();
-    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
     const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
     const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU;
@@ -276,6 +336,27 @@ gemm_conv_kernel(const Params p) {
                 }
         }
     };
+    // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
+    if constexpr (LW) {
+        ln_reduce();                                   // ---- math waves: LDS reads + MFMA only
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
+            compute(cur);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+        }
+    } else {
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    ln_reduce();
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + NS - 1 < nk;
@@ -287,6 +368,7 @@ gemm_conv_kernel(const Params p) {
         asm volatile("" ::: "memory");
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
     }
 
     // ---------------------------------------------------------------- fused LayerNorm (consumer side), part 2
@@ -468,13 +550,15 @@ struct TileCfg { int bm, bn; };
 // SIMD, so MFMA utilisation is set by MFMAs per non-MFMA instruction, i.e. by the wave tile.
 // 7 = 128x160 (4 waves of 32x160, 2 stages): N = 1280 / 640 split into 160-wide tiles gives exactly 256 / 512 tiles
 // for this path's M = 4096 / 16384 GEMMs, i.e. whole rounds on 256 CUs instead of 1.25 / 2.5.
-constexpr int NUM_CFG = 7;
+// 8..11 = tilings 7, 2, 1, 4 with one extra LOADER wave (wave specialisation, see gemm_conv_kernel); the 4-wave tilings
+// with 128-wide wave tiles (5, 6) have no registers for a fifth wave on one of the SIMDs
+constexpr int NUM_CFG = 11;
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV>
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     constexpr int SMEM = NS * (BM + BN) * 128 + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
     static bool attr_set = false;   // idempotent; racing threads set the same value
-    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV>;
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -484,7 +568,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     p.group_m = BM >= 256 ? 4 : 8;
     if (BM >= 256 && BN >= 256) p.group_m = 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
-    kern<<<grid, WM * WN * 64, SMEM, st>>>(p);
+    kern<<<grid, (WM * WN + LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
@@ -499,7 +583,10 @@ int pick_cfg(const Params& p, int batch) {
 template <int CONV>
 int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
-    if ((cfg == 4 || cfg == 5 || cfg == 7) && p.n_trans_begin >= 0) cfg = 2;   // transposed stores need square wave tiles
+    if (p.n_trans_begin >= 0) {                                                // transposed stores need square wave tiles
+        if (cfg == 4 || cfg == 5 || cfg == 7) cfg = 2;
+        if (cfg == 8 || cfg == 11) cfg = 9;
+    }
     switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 2, CONV>(p, batch, st);
     case 2: return launch_cfg<256, 128, 4, 2, 3, CONV>(p, batch, st);
@@ -507,14 +594,34 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
     case 4: return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
     case 5: return launch_cfg<256, 128, 2, 2, 3, CONV>(p, batch, st);
     case 6: return launch_cfg<256, 256, 2, 2, 2, CONV>(p, batch, st);
-    default: return launch_cfg<128, 160, 4, 1, 2, CONV>(p, batch, st);
+    case 7: return launch_cfg<128, 160, 4, 1, 2, CONV>(p, batch, st);
+    default: break;
+    }
+    // loader-wave variants exist for the plain GEMM only: the im2col gather's per-row offset tables do not fit the loader's
+    // register budget (the compiler falls back to scratch and waterfall loops, 5x slower), and the conv mainloop already
+    // runs at 0.8-1.0 PFLOP/s -- conv launches fall back to the tiling without the loader
+    if constexpr (CONV) {
+        switch (cfg) {
+        case 8: return launch_cfg<128, 160, 4, 1, 2, CONV>(p, batch, st);
+        case 9: return launch_cfg<256, 128, 4, 2, 3, CONV>(p, batch, st);
+        case 10: return launch_cfg<128, 128, 2, 2, 2, CONV>(p, batch, st);
+        default: return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
+        }
+    } else {
+        switch (cfg) {
+        case 8: return launch_cfg<128, 160, 4, 1, 2, CONV, 1>(p, batch, st);
+        case 9: return launch_cfg<256, 128, 4, 2, 3, CONV, 1>(p, batch, st);
+        case 10: return launch_cfg<128, 128, 2, 2, 2, CONV, 1>(p, batch, st);
+        default: return launch_cfg<256, 256, 2, 4, 2, CONV, 1>(p, batch, st);
+        }
     }
 }
 
 }  // namespace
 
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
-    static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160}};
+    static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
+                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

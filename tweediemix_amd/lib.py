@@ -15,7 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
 CONV_S1, CONV_S2, CONV_UP2 = 0, 1, 2
-TILE_AUTO, TILE_COUNT = 0, 7
+TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 11, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

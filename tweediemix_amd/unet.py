@@ -360,10 +360,14 @@ class UNetPlan:
             idx = {i: n for n, (i, _k, _d) in enumerate(tun)}
             st = torch.cuda.current_stream().cuda_stream
             best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
+            # the loader-wave tilings (8..11) win isolated launches by 7-27 % and in-sequence eager launches by 2-4 %, but a
+            # 9-wave / 147 KB workgroup owns its CU: in graph replay the next kernel (or the other chain) cannot move in
+            # while it drains, and whole steps came out 0-3 % SLOWER -- so they are candidates only on request
+            ncand_gemm = L.TILE_COUNT if os.environ.get("TMIX_TUNE_LW") else L.TILE_COUNT_CONV
             for _rep in range(reps):
-                for cfg in range(1, L.TILE_COUNT + 1):
-                    for _i, _k, d in tun:
-                        d.tile_cfg = cfg
+                for cfg in range(1, ncand_gemm + 1):
+                    for _i, kind, d in tun:
+                        d.tile_cfg = cfg if (kind == "gemm" or cfg <= L.TILE_COUNT_CONV) else 1
                     self._link_ln()
                     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in tun]
                     for i, (fn, args) in enumerate(self.ops):
@@ -383,7 +387,8 @@ class UNetPlan:
                         best_t[(k, cfg)] = min(best_t.get((k, cfg), float("inf")), t)
             for k in set(keys):
                 if k not in _TUNE_CACHE:
-                    _TUNE_CACHE[k] = min(range(1, L.TILE_COUNT + 1), key=lambda c: best_t[(k, c)])
+                    ncand = ncand_gemm if k.startswith("('gemm'") else L.TILE_COUNT_CONV
+                    _TUNE_CACHE[k] = min(range(1, ncand + 1), key=lambda c: best_t[(k, c)])
         for (_i, _kind, d), k in zip(tun, keys):
             d.tile_cfg = _TUNE_CACHE[k]
         self._link_ln()
