@@ -137,12 +137,14 @@ def main(argv=None):
             assert K_text == K, (K_text, K)
     W = U.UNetWeights(cfg, sd, opt.device, (kind, con))
     h, w = opt.resolution_h // 8, opt.resolution_w // 8
+    sidecar = False
     if opt.mask_paths:
         fg = opt.mask_paths.split('+')
     elif opt.random_masks or opt.synthetic:
         fg = M.random_rectangle_masks(K, opt.resolution_h, opt.resolution_w, seed=opt.seed)
-    else:   # the reference's file contract: the side-car wrote '<seg_concept>.jpg' under output_path (:461-466)
+    else:   # the reference's file contract (:453-466): the side-car writes '<seg_concept>.jpg' under output_path
         fg = [os.path.join(opt.output_path, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
+        sidecar = True
     vae = None
     vae_dir = opt.vae_path or (opt.sd_path and os.path.isdir(os.path.join(opt.sd_path, 'vae')) and os.path.join(opt.sd_path, 'vae'))
     if vae_dir:
@@ -160,6 +162,12 @@ def main(argv=None):
         vae = (V.TINY, V.synthetic_state_dict(V.TINY))
     tw = S.Tweediemix(opt, W, te, ts, lambda x0: M.build_masks(fg, h, w, opt.device), concept_num=K, lora=LORA,
                       use_graphs=not opt.no_graphs, n_seeds=opt.num_seeds, n_streams=opt.streams, vae=vae)
+    if sidecar and vae is not None:
+        # with a VAE the whole contract runs like the reference: decode the Tweedie preview to {output_path}/tweedie.jpg,
+        # call `CUDA_VISIBLE_DEVICES={seg_gpu} python text_segment/run_expand.py ...` (TMIX_SEG_CMD overrides the command),
+        # read the masks back; without one the mask files must already be there
+        tw.mask_provider = M.SidecarMaskProvider(tw, opt.output_path, opt.seg_concepts, seg_gpu=opt.seg_gpu,
+                                                 cmd_template=os.environ.get('TMIX_SEG_CMD'))
     x = torch.randn(opt.num_seeds, 4, h, w)             # CPU draw after seed_everything, like :488
     lat = tw.run_fusion(x)
     os.makedirs(opt.output_path_all, exist_ok=True)
