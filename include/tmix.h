@@ -124,10 +124,12 @@ int tmix_gemm_stats_parts(int N, int tile_cfg);
  * Replaces diffusers ResnetBlock2D.conv1/conv2, Downsample2D.conv (mode 1) and Upsample2D
  * (nearest x2 + conv, mode 2) inside the same UNet call sites.  Cin % 64 == 0.
  */
-enum { TMIX_CONV_S1 = 0, TMIX_CONV_S2 = 1, TMIX_CONV_UP2 = 2 };
+/* TMIX_CONV_T3: temporal convolution, kernel (3,1,1) with padding (1,0,0) over the FIRST spatial axis -- X is
+ * [clips][frames][h*w][Cin] and Wt [Cout][3][Cin] (diffusers TemporalConvLayer's Conv3d of the I2VGen-XL UNet, config #5). */
+enum { TMIX_CONV_S1 = 0, TMIX_CONV_S2 = 1, TMIX_CONV_UP2 = 2, TMIX_CONV_T3 = 3 };
 typedef struct {
     const void* X;   /* bf16 [B][H][W][Cin]                                   */
-    const void* Wt;  /* bf16 [Cout][3][3][Cin]                                */
+    const void* Wt;  /* bf16 [Cout][3][3][Cin]  ([Cout][3][Cin] for T3)       */
     void*       Y;   /* bf16 [B][Ho][Wo][Cout]  Ho = H (S1), H/2 (S2), 2H (UP2) */
     const float* bias;           /* fp32 [Cout] or NULL                       */
     const float* batch_bias;     /* fp32 [B][Cout] (time embedding) or NULL   */
@@ -186,6 +188,12 @@ int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64
  * S is a stack of [seq][cols] score blocks; row r sees columns <= r % seq, every other column (padding included) gets 0. */
 int tmix_softmax_rows_causal(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale,
                              int seq, void* stream);
+/* temporal self-attention over the frame axis (diffusers TransformerTemporalModel of the I2VGen-XL UNet, BASELINE config #5;
+ * the reference drives it through video_gen/pipeline_i2vgen_xl.py:688-697): QKV bf16 [(clips*frames)][hw][ld] with columns
+ * [0,C) = Q, [C,2C) = K, [2C,3C) = V, C = heads*64; every (clip, pixel, head) attends over its <= 16 frames;
+ * O bf16 [(clips*frames)][hw][ldo], columns [0,C). */
+int tmix_temporal_attn(const void* QKV, int64_t ld, void* O, int64_t ldo, int clips, int frames, int64_t hw, int heads,
+                       float scale, void* stream);
 /* y = clamp(x*scale + shift, lo, hi) on fp32 (image post-processing (img/2+0.5).clamp(0,1), fusion_sampling.py:302) */
 int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
 /* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 16.

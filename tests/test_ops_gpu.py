@@ -320,3 +320,33 @@ def test_gemm_fused_layernorm_pair(ops, cfg):
     z4 = F.layer_norm(hf, (C1,), gamma, beta, 1e-5) @ w4.float().T
     close(qk[0], z4[:, :2 * C1], rtol=2 ** -6, atol_frac=4e-3)
     close(vt[0, :, :M], z4[:, 2 * C1:].T, rtol=2 ** -6, atol_frac=4e-3)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 7])
+def test_conv_temporal_3x1x1(ops, cfg):
+    """TMIX_CONV_T3 against F.conv3d with a (3,1,1) kernel and (1,0,0) padding (diffusers TemporalConvLayer):
+    x [clips, frames, h*w, C] <-> torch [clips, C, frames, h, w]."""
+    from tweediemix_amd import lib as L
+    clips, frames, h, w, Ci, Co = 2, 16, 6, 5, 128, 192
+    x = rnd(clips, frames, h * w, Ci, seed=90)
+    wt = rnd(Co, 3, Ci, seed=91, scale=(3 * Ci) ** -0.5)
+    bias = rnd(Co, seed=92, dtype=torch.float32)
+    res = rnd(clips, frames, h * w, Co, seed=93)
+    y = ops.conv3x3(x, wt, bias=bias, residual=res, mode=L.CONV_T3, tile_cfg=cfg)
+    xt = x.float().view(clips, frames, h, w, Ci).permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xt, wt.float().permute(0, 2, 1)[:, :, :, None, None], bias, padding=(1, 0, 0))
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(clips, frames, h * w, Co) + res.float()
+    close(y, ref, rtol=2 ** -6, atol_frac=4e-3)
+
+
+@pytest.mark.parametrize("frames", [16, 9])
+def test_temporal_attention(ops, frames):
+    """tmix_temporal_attn against torch softmax attention over the frame axis ([b*hw, heads, frames, 64])."""
+    clips, hw, heads = 2, 37, 5
+    C = heads * 64
+    qkv = rnd(clips * frames, hw, 3 * C, seed=95)
+    out = ops.temporal_attention(qkv, clips, frames, heads)
+    x = qkv.float().view(clips, frames, hw, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)      # [3, clips, hw, heads, frames, 64]
+    ref = F.scaled_dot_product_attention(x[0], x[1], x[2])                               # over frames
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(clips * frames, hw, C)
+    close(out, ref, rtol=2 ** -6, atol_frac=4e-3)

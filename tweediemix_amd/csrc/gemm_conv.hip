@@ -43,7 +43,7 @@ struct Params {
     const float* ln_stats; int64_t strideLnStats, ldLnStats; const float* ln_colsum; int64_t strideLnColsum;   // consumer side
     float ln_inv_c, ln_eps; int ln_parts;
     // convolution geometry (CONV only)
-    int H, Wd, Cin, Ho, Wo, mode;
+    int H, Wd, Cin, Ho, Wo, mode, ntaps;
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -167,11 +167,12 @@ gemm_conv_kernel(const Params p) {
     // the channel chunk rides in the scalar soffset.  Padding taps get an offset beyond num_records (-> zeros).
     unsigned cvo[RA];
     auto conv_tap_offsets = [&]() {
-        const int ky = tap / 3, kx = tap - ky * 3;
+        // TMIX_CONV_T3: a (3,1,1) kernel over the first (frame) axis only -- 3 taps, kx fixed at the centre
+        const int ky = p.mode == TMIX_CONV_T3 ? tap : tap / 3, kx = p.mode == TMIX_CONV_T3 ? 1 : tap - ky * 3;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             int iy, ix; bool ok;
-            if (p.mode == TMIX_CONV_S1)      { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            if (p.mode == TMIX_CONV_S1 || p.mode == TMIX_CONV_T3) { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
             else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
             else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
                    ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
@@ -197,7 +198,7 @@ gemm_conv_kernel(const Params p) {
                                      (unsigned)kt * (BK * 2), sW + r * 1024);
             else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + (r * SW + sw_id) * 1024);
         }
-        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < 9) conv_tap_offsets(); } }
+        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < p.ntaps) conv_tap_offsets(); } }
     };
 
     // ---- loader wave (LW): leaves here, before any math-wave state (accumulators, fragments) becomes live
@@ -681,27 +682,28 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: empty problem");
     if (d->Cin % BK) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: Cin=%d must be a multiple of %d", d->Cin, BK);
     if (d->Cout % 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: Cout=%d must be a multiple of 4", d->Cout);
-    if (d->mode < TMIX_CONV_S1 || d->mode > TMIX_CONV_UP2) TMIX_FAIL(TMIX_EINVAL, "conv3x3: bad mode %d", d->mode);
+    if (d->mode < TMIX_CONV_S1 || d->mode > TMIX_CONV_T3) TMIX_FAIL(TMIX_EINVAL, "conv3x3: bad mode %d", d->mode);
     if (d->mode == TMIX_CONV_S2 && ((d->H | d->W) & 1)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: stride-2 needs even H,W");
     if (!aligned16(d->X) || !aligned16(d->Wt) || (((uintptr_t)d->Y) & 7)) TMIX_FAIL(TMIX_EALIGN, "conv3x3: pointer alignment");
     if ((d->bias && (((uintptr_t)d->bias) & 15)) || (d->batch_bias && (((uintptr_t)d->batch_bias) & 15))) TMIX_FAIL(TMIX_EALIGN, "conv3x3: bias alignment");
     Params p = {};
     p.H = d->H; p.Wd = d->W; p.Cin = d->Cin; p.mode = d->mode;
+    p.ntaps = d->mode == TMIX_CONV_T3 ? 3 : 9;
     p.Ho = d->mode == TMIX_CONV_S2 ? d->H / 2 : (d->mode == TMIX_CONV_UP2 ? d->H * 2 : d->H);
     p.Wo = d->mode == TMIX_CONV_S2 ? d->W / 2 : (d->mode == TMIX_CONV_UP2 ? d->W * 2 : d->W);
     const int64_t M = (int64_t)d->B * p.Ho * p.Wo;
     if (M > 0x7fffffff / 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: too many output pixels");
     if ((int64_t)d->B * d->H * d->W * d->Cin >= (1ll << 30) || (int64_t)d->Cout * 9 * d->Cin >= (1ll << 30)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: operand larger than 2 GiB");
     p.A = (const bf16_t*)d->X;
-    p.W = (const bf16_t*)d->Wt; p.ldw = 9 * (int64_t)d->Cin;
+    p.W = (const bf16_t*)d->Wt; p.ldw = p.ntaps * (int64_t)d->Cin;
     p.C = (bf16_t*)d->Y; p.ldc = d->Cout;
     p.bias = d->bias;
     p.R = (const bf16_t*)d->residual; p.ldr = d->Cout;
     p.rgb = d->batch_bias; p.rows_per_group = p.Ho * p.Wo;
     p.n_trans_begin = -1;
-    p.M = (int)M; p.N = d->Cout; p.K = 9 * d->Cin;
+    p.M = (int)M; p.N = d->Cout; p.K = p.ntaps * d->Cin;
     p.epilogue = TMIX_EPI_NONE;
     p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
-    p.bytesW = (unsigned)((int64_t)d->Cout * 9 * d->Cin * 2);
+    p.bytesW = (unsigned)((int64_t)d->Cout * p.ntaps * d->Cin * 2);
     return launch<1>(p, 1, d->tile_cfg, (hipStream_t)stream);
 }

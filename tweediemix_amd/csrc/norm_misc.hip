@@ -464,6 +464,92 @@ extern "C" int tmix_concat_channels(const void* X1, int C1, const void* X2, int 
     return TMIX_OK;
 }
 
+// ------------------------------------------------------------------------------ temporal attention (frame axis, S <= 16)
+// I2VGen-XL's TransformerTemporalModel attends over the FRAMES of one pixel: sequences of 16 tokens, head size 64, one
+// (clip, pixel, head) item per wave.  Lane = (query frame i = lane & 15, 16-wide slice c = lane >> 4 of the head dimension).
+namespace {
+__global__ void __launch_bounds__(256) temporal_attn_kernel(const bf16_t* __restrict__ QKV, int64_t ld, bf16_t* __restrict__ O, int64_t ldo,
+                                                            int frames, int64_t hw, int heads, int64_t items, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK[4][16][64], sV[4][16][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + w;
+    const bool live = item < items;
+    const int C = heads * 64;
+    const int i = lane & 15, c = lane >> 4;
+    const int64_t ph = live ? item : 0;
+    const int h = (int)(ph % heads);
+    const int64_t cp = ph / heads;                                   // clip * hw + pixel
+    const int64_t clip = cp / hw, pix = cp - clip * hw;
+    const int64_t row = (clip * frames + (i < frames ? i : 0)) * hw + pix;      // token row of frame i
+    const bf16_t* q = QKV + row * ld + h * 64 + c * 16;
+    uint4 qa = *(const uint4*)q, qb = *(const uint4*)(q + 8);
+    *(uint4*)&sK[w][i][c * 16] = *(const uint4*)(q + C);
+    *(uint4*)&sK[w][i][c * 16 + 8] = *(const uint4*)(q + C + 8);
+    *(uint4*)&sV[w][i][c * 16] = *(const uint4*)(q + 2 * C);
+    *(uint4*)&sV[w][i][c * 16 + 8] = *(const uint4*)(q + 2 * C + 8);
+    __syncthreads();
+    float qf[16];
+    {
+        const unsigned u[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { qf[2 * d] = bf2f((bf16_t)(u[d] & 0xffff)) * scale_log2e; qf[2 * d + 1] = bf2f((bf16_t)(u[d] >> 16)) * scale_log2e; }
+    }
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float a = 0.f;
+        const uint4 ka = *(const uint4*)&sK[w][j][c * 16], kb = *(const uint4*)&sK[w][j][c * 16 + 8];
+        const unsigned u[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { a = fmaf(qf[2 * d], bf2f((bf16_t)(u[d] & 0xffff)), a); a = fmaf(qf[2 * d + 1], bf2f((bf16_t)(u[d] >> 16)), a); }
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        sc[j] = j < frames ? a : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { sc[j] = exp2f(sc[j] - mx); sum += sc[j]; }
+    const float inv = 1.0f / sum;
+    float o[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint4 va = *(const uint4*)&sV[w][j][c * 16], vb = *(const uint4*)&sV[w][j][c * 16 + 8];
+        const unsigned u[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const float pj = sc[j];                                       // 0 for padded frames
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { o[2 * d] = fmaf(pj, bf2f((bf16_t)(u[d] & 0xffff)), o[2 * d]); o[2 * d + 1] = fmaf(pj, bf2f((bf16_t)(u[d] >> 16)), o[2 * d + 1]); }
+    }
+    if (live && i < frames) {
+        uint4 a, b;
+        a.x = pack_bf2(o[0] * inv, o[1] * inv);   a.y = pack_bf2(o[2] * inv, o[3] * inv);
+        a.z = pack_bf2(o[4] * inv, o[5] * inv);   a.w = pack_bf2(o[6] * inv, o[7] * inv);
+        b.x = pack_bf2(o[8] * inv, o[9] * inv);   b.y = pack_bf2(o[10] * inv, o[11] * inv);
+        b.z = pack_bf2(o[12] * inv, o[13] * inv); b.w = pack_bf2(o[14] * inv, o[15] * inv);
+        bf16_t* dst = O + row * ldo + h * 64 + c * 16;
+        *(uint4*)dst = a; *(uint4*)(dst + 8) = b;
+    }
+}
+}  // namespace
+
+extern "C" int tmix_temporal_attn(const void* QKV, int64_t ld, void* O, int64_t ldo, int clips, int frames, int64_t hw, int heads,
+                                  float scale, void* stream) {
+    if (!QKV || !O) TMIX_FAIL(TMIX_EINVAL, "temporal_attn: null pointer");
+    if (clips < 1 || frames < 1 || frames > 16 || hw < 1 || heads < 1) TMIX_FAIL(TMIX_ESHAPE, "temporal_attn: clips=%d frames=%d (1..16) hw=%lld heads=%d", clips, frames, (long long)hw, heads);
+    if (ld < 3 * heads * 64 || ldo < heads * 64 || (ld % 8) || (ldo % 8)) TMIX_FAIL(TMIX_ESHAPE, "temporal_attn: ld=%lld ldo=%lld for %d heads of 64", (long long)ld, (long long)ldo, heads);
+    if (!aligned16(QKV) || !aligned16(O)) TMIX_FAIL(TMIX_EALIGN, "temporal_attn: pointers must be 16-byte aligned");
+    const int64_t items = (int64_t)clips * hw * heads;
+    const int64_t blocks = (items + 3) / 4;
+    if (blocks > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "temporal_attn: grid too large");
+    temporal_attn_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)QKV, ld, (bf16_t*)O, ldo, frames, hw, heads, items,
+                                                                            scale * 1.4426950408889634f);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
 extern "C" int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale, void* stream) {
     if (!S || !P) TMIX_FAIL(TMIX_EINVAL, "softmax_rows: null pointer");
     if (rows <= 0 || cols <= 0 || (cols % 4) || (ld_s % 4) || (ld_p % 4)) TMIX_FAIL(TMIX_ESHAPE, "softmax_rows: rows=%lld cols=%d (cols, ld %% 4 == 0)", (long long)rows, cols);

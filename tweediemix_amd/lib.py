@@ -14,7 +14,7 @@ OK, EINVAL, ESHAPE, EARCH, EALIGN = 0, -1, -2, -3, -4
 F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
-CONV_S1, CONV_S2, CONV_UP2 = 0, 1, 2
+CONV_S1, CONV_S2, CONV_UP2, CONV_T3 = 0, 1, 2, 3
 TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 11, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -66,6 +66,7 @@ SIGNATURES = {
                                       C.c_int, vp]),
     "tmix_layernorm": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, f32, vp]),
     "tmix_zero": (C.c_int, [vp, i64, vp]),
+    "tmix_temporal_attn": (C.c_int, [vp, i64, vp, i64, C.c_int, C.c_int, i64, C.c_int, f32, vp]),
     "tmix_vpred_step": (C.c_int, [vp, vp, vp, C.c_int, i64, f32, f32, f32, f32, f32, vp]),
     "tmix_frame_inject": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64, C.c_int, f32, f32, vp]),
     "tmix_gemm_tile_shape": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

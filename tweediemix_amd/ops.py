@@ -142,11 +142,12 @@ def gemm(a, w, out=None, **kw):
 
 
 def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0):
-    """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous."""
+    """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous ([Cout,3,Cin] for the temporal CONV_T3,
+    where x is [clips, frames, h*w, Cin])."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     assert x.dtype == BF16 and w.dtype == BF16 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
-    assert tuple(w.shape) == (Cout, 3, 3, Cin)
+    assert tuple(w.shape) == ((Cout, 3, Cin) if mode == L.CONV_T3 else (Cout, 3, 3, Cin))
     d = L.ConvDesc()
     d.X, d.Wt, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.batch_bias, d.residual = _p(bias), _p(batch_bias), _p(residual)
@@ -315,3 +316,15 @@ def frame_inject(x, clips, frames, interp=None):
     b = 0.0 if hard else float(np.float32(1.0 - float(interp)))
     L.check(L.load().tmix_frame_inject(_p(x), _EPS_DT[x.dtype], clips, frames, per, int(hard), a, b, _stream()), "tmix_frame_inject")
     return x
+
+
+def temporal_attention(qkv, clips, frames, heads, scale=None, out=None):
+    """self-attention over the frame axis: qkv [(clips*frames), hw, 3*heads*64] bf16 -> [(clips*frames), hw, heads*64]."""
+    _need_cuda(qkv)
+    n, hw, ld = qkv.shape
+    C3 = 3 * heads * 64
+    assert n == clips * frames and qkv.dtype == BF16 and qkv.stride(2) == 1 and qkv.stride(0) == hw * qkv.stride(1) and ld >= C3
+    out = torch.empty(n, hw, heads * 64, device=qkv.device, dtype=BF16) if out is None else out
+    L.check(L.load().tmix_temporal_attn(_p(qkv), qkv.stride(1), _p(out), out.stride(1), clips, frames, hw, heads,
+                                        float(scale if scale is not None else 64 ** -0.5), _stream()), "tmix_temporal_attn")
+    return out
