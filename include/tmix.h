@@ -136,6 +136,8 @@ typedef struct {
     const void* residual;        /* bf16 like Y or NULL                       */
     int32_t B, H, W, Cin, Cout, mode;
     int32_t tile_cfg;            /* TMIX_TILE_*                                */
+    int32_t batch_bias_images;   /* consecutive images that share one batch_bias row (0/1: one row per image; the video
+                                    UNet folds frames into B and has one time embedding per clip: = frames) */
 } tmix_conv_desc;
 int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
 

@@ -1,0 +1,84 @@
+"""The I2VGen-XL UNet plan (tweediemix_amd/i2vgen.py) against oracle/i2vgen_oracle.py (fp32 torch restatement; parity
+UNPINNED, see its header) on a tiny configuration, plus the inventory check of the full-size model."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm())
+
+
+def _setup(cfg_o, cfg_p, B, Fr, H, W, Lk):
+    from oracle import i2vgen_oracle as IO
+    sd = IO.synthetic_state_dict(cfg_o)
+    sd = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(0)
+    il = torch.randn(B, 4, Fr, H, W, generator=g)
+    emb = torch.randn(B, cfg_o.cross_dim, generator=g)
+    ehs = torch.randn(B, Lk, cfg_o.cross_dim, generator=g)
+    fps = torch.tensor([8.0] * B)
+    sample = torch.randn(B, 4, Fr, H, W, generator=g)
+    return sd, il, emb, ehs, fps, sample
+
+
+def test_conditioning_and_plan_match_oracle_tiny():
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I
+    B, Fr, H, W, Lk = 2, 16, 16, 8, 13
+    sd, il, emb, ehs, fps, sample = _setup(IO.TINY, I.TINY, B, Fr, H, W, Lk)
+    Wt = I.I2VWeights(I.TINY, sd)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    fe_o, ctx_o, ilf_o = IO.conditioning(sd, IO.TINY, fps, il, emb, ehs)
+    assert rel(fe, fe_o) < 1e-4 and rel(ctx, ctx_o) < 1e-4 and rel(ilf, ilf_o) < 1e-4
+    assert ctx.shape == (B, Lk + (IO.TINY.ctx_pool // 4) ** 2 + 4, IO.TINY.cross_dim)
+    plan = I.I2VPlan(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    out = plan(sample, 981).clone()
+    want = IO.forward(sd, IO.TINY, sample, 981, fe_o, ctx_o, ilf_o)
+    assert out.shape == want.shape == (B, 4, Fr, H, W)
+    assert rel(out, want) < 2e-2, rel(out, want)
+    out2 = plan(sample, 981)
+    assert torch.equal(out, out2)                                  # deterministic replay
+
+
+def test_full_size_inventory():
+    """the restated I2VGenXLUNet has 1,420,469,224 parameters (2.84 GB in fp16, the size of the published fp16 checkpoint)
+    and every key maps into the kernel-layout container."""
+    from oracle import i2vgen_oracle as IO
+    shapes = IO.param_shapes(IO.FULL)
+    assert sum(torch.Size(s).numel() for s in shapes.values()) == 1_420_469_224
+
+
+def test_full_architecture_small_frames_match_oracle():
+    """the real channel / head / layer configuration (1.42 B parameters) on 2 clips x 16 frames of 16x16 latents."""
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I
+    B, Fr, H, W, Lk = 2, 16, 16, 16, 77
+    sd, il, emb, ehs, fps, sample = _setup(IO.FULL, I.FULL, B, Fr, H, W, Lk)
+    Wt = I.I2VWeights(I.FULL, sd)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    assert ctx.shape == (B, 77 + 64 + 4, 1024)
+    plan = I.I2VPlan(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    out = plan(sample, 501).clone()
+    fe_o, ctx_o, ilf_o = IO.conditioning(sd, IO.FULL, fps, il, emb, ehs)
+    want = IO.forward(sd, IO.FULL, sample, 501, fe_o, ctx_o, ilf_o)
+    r = rel(out, want)
+    print("I2VGen-XL full architecture rel-L2 vs fp32 restatement:", r)
+    assert r < 2e-2, r
+
+
+def test_video_loop_on_the_plan():
+    """tweediemix_amd.video.sample_loop driving the plan: CFG batch of 2 clips, v-prediction update, injection hooks off."""
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I, video as V
+    import numpy as np
+    B, Fr, H, W = 2, 16, 16, 8
+    sd, il, emb, ehs, fps, sample = _setup(IO.TINY, I.TINY, B, Fr, H, W, 13)
+    Wt = I.I2VWeights(I.TINY, sd)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    plan = I.I2VPlan(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    acp = np.cos((np.arange(1000) / 1000 + 0.008) / 1.008 * np.pi / 2) ** 2
+    sch = V.VideoSchedule(acp.astype(np.float32), 5)
+    x = V.sample_loop(lambda xin, t: plan(xin, t).contiguous(), sample[:1].cuda(), sch, 9.0)
+    assert x.shape == (1, 4, Fr, H, W) and torch.isfinite(x).all()

@@ -699,7 +699,7 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.C = (bf16_t*)d->Y; p.ldc = d->Cout;
     p.bias = d->bias;
     p.R = (const bf16_t*)d->residual; p.ldr = d->Cout;
-    p.rgb = d->batch_bias; p.rows_per_group = p.Ho * p.Wo;
+    p.rgb = d->batch_bias; p.rows_per_group = p.Ho * p.Wo * (d->batch_bias_images > 1 ? d->batch_bias_images : 1);
     p.n_trans_begin = -1;
     p.M = (int)M; p.N = d->Cout; p.K = p.ntaps * d->Cin;
     p.epilogue = TMIX_EPI_NONE;

@@ -611,17 +611,19 @@ extern "C" int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const 
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv_in: bad shape");
     if (!aligned16(y_nhwc)) TMIX_FAIL(TMIX_EALIGN, "conv_in: output must be 16-byte aligned");
     if (Cout % 32) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d must be a multiple of 32", Cout);
-    if (Cin != 4) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (only the 4-channel latent is supported)", Cin);
+    if (Cin != 4 && Cin != 8) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (4: image latent, 8: video latent + image-latent features)", Cin);
+    if (Cin == 8 && pre_w) TMIX_FAIL(TMIX_EINVAL, "conv_in: the latent pre-map is defined for 4 channels");
     if (!aligned16(w_ohwi)) TMIX_FAIL(TMIX_EALIGN, "conv_in: weights must be 16-byte aligned");
     const int64_t npix = (int64_t)B * H * W;
     const unsigned nb = (unsigned)((npix + 63) / 64);
-    const int smem = Cout * 36 * 4;
+    const int smem = Cout * 9 * Cin * 4;
     if (smem > 150 * 1024) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d too large for the LDS weight stage", Cout);
-    static int attr_smem = 0;
-    if (smem > 64 * 1024 && smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_in_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static int attr_smem[2] = {0, 0};
+    if (smem > 64 * 1024 && smem > attr_smem[Cin == 8]) {
+        hipError_t e = Cin == 8 ? hipFuncSetAttribute((const void*)conv_in_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)
+                                : hipFuncSetAttribute((const void*)conv_in_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_smem = smem;
+        attr_smem[Cin == 8] = smem;
     }
     PreMap pm = {};
     if (pre_w) {
@@ -630,7 +632,8 @@ extern "C" int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const 
         for (int i = 0; i < 4; ++i) pm.b[i] = pre_b ? pre_b[i] : 0.f;
     }
     hipStream_t st = (hipStream_t)stream;
-    conv_in_kernel<4><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
+    if (Cin == 8) conv_in_kernel<8><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
+    else          conv_in_kernel<4><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }

@@ -1,0 +1,392 @@
+"""The I2VGen-XL UNet (BASELINE config #5; the network behind video_gen/pipeline_i2vgen_xl.py:688-697) on this package's HIP
+kernels: the spatial skeleton reuses the SDXL plan's emitters (ResnetBlock2D, Transformer2DModel with cached cross-attention
+K/V, GroupNorm, implicit-GEMM convs) with the frames folded into the batch; the temporal layers run on the same GEMM /
+GroupNorm kernels over the frame axis plus `TMIX_CONV_T3` (TemporalConvLayer) and `tmix_temporal_attn`
+(TransformerTemporalModel).  Everything that does not depend on the sample or the timestep (fps / context / image-latent
+embeddings: a handful of 4..64-channel convolutions and one 4-wide temporal encoder) is evaluated ONCE per video by
+`conditioning()` below with stock torch ops -- init-time, outside the per-step path.
+
+PARITY UNPINNED (diffusers is neither vendored in the reference nor installed here; no checkpoint offline): structure and
+key names follow the published `I2VGenXLUNet`; the restated inventory has 1,420,469,224 parameters = 2.84 GB in fp16, the
+size of the published fp16 checkpoint.  Tests compare this plan with oracle/i2vgen_oracle.py (the fp32 restatement)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops
+from .unet import UNetPlan, _Arena, BF16, F32
+from .weights import fold_layernorm, interleave_geglu
+
+
+@dataclass
+class I2VConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: tuple = (320, 640, 1280, 1280)
+    attn_levels: tuple = (True, True, True, False)
+    layers_per_block: int = 2
+    norm_groups: int = 32
+    cross_dim: int = 1024
+    head_dim: int = 64
+    transformer_in_heads: int = 8
+    ctx_pool: int = 32
+
+    @property
+    def time_embed_dim(self):
+        return self.block_out_channels[0] * 4
+
+
+FULL = I2VConfig()
+TINY = I2VConfig(block_out_channels=(64, 128, 128, 128), cross_dim=128, transformer_in_heads=2, ctx_pool=8)
+
+
+def _sites(cfg):
+    """(spatial t2d prefixes, temporal transformer prefixes with (channels, inner)) in forward order."""
+    ch, nb = cfg.block_out_channels, len(cfg.block_out_channels)
+    t2d, tt = [], [("transformer_in", ch[0], cfg.transformer_in_heads * cfg.head_dim)]
+    for bi, co in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            if cfg.attn_levels[bi]:
+                t2d.append((f"down_blocks.{bi}.attentions.{j}", co)); tt.append((f"down_blocks.{bi}.temp_attentions.{j}", co, co))
+    t2d.append(("mid_block.attentions.0", ch[-1])); tt.append(("mid_block.temp_attentions.0", ch[-1], ch[-1]))
+    for ui in range(nb):
+        bi = nb - 1 - ui
+        for j in range(cfg.layers_per_block + 1):
+            if cfg.attn_levels[bi]:
+                t2d.append((f"up_blocks.{ui}.attentions.{j}", ch[bi])); tt.append((f"up_blocks.{ui}.temp_attentions.{j}", ch[bi], ch[bi]))
+    return t2d, tt
+
+
+class I2VWeights:
+    """device-resident weights in kernel layouts from a diffusers-keyed I2VGenXLUNet state dict."""
+
+    def __init__(self, cfg: I2VConfig, sd: dict, device="cuda"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.kind, self.K = "none", 0
+        dev = self.device
+        self.raw = {k: v for k, v in sd.items() if k.startswith(("image_latents_", "context_embedding", "fps_embedding"))}
+        t = {}
+        g = lambda n: sd[n].to(dev)
+        bf = lambda x: x.to(dev, BF16).contiguous()
+        f32 = lambda x: x.to(dev, F32).contiguous()
+        for name, v in sd.items():
+            if name in self.raw or name == "conv_in.weight":
+                continue
+            if name.endswith(".bias") or v.dim() == 1:
+                t[name] = f32(v)
+            elif v.dim() == 5:                                   # Conv3d (3,1,1): [Co,Ci,3,1,1] -> [Co,3,Ci]
+                t[name] = bf(v.to(dev)[:, :, :, 0, 0].permute(0, 2, 1))
+            elif v.dim() == 4 and v.shape[-1] == 3:
+                t[name] = bf(v.to(dev).permute(0, 2, 3, 1))
+            elif v.dim() == 4:                                   # 1x1 conv_shortcut -> Linear
+                t[name] = bf(v.to(dev).reshape(v.shape[0], v.shape[1]))
+            elif v.dim() == 2 and ".attn" not in name and ".ff.net.0.proj" not in name:
+                t[name] = bf(v)
+        t["conv_in.weight"] = f32(g("conv_in.weight").permute(0, 2, 3, 1))
+
+        def fold(key, w, norm, bias=None):
+            wp, cs, tt = fold_layernorm(w.to(dev, F32), g(norm + ".weight"), g(norm + ".bias"), bias)
+            t[key], t[key + ".colsum"], t[key + ".bias"] = wp, cs, tt
+
+        def ff(tb):
+            wp, cs, tt = fold_layernorm(g(tb + ".ff.net.0.proj.weight").to(F32), g(tb + ".norm3.weight"), g(tb + ".norm3.bias"),
+                                        g(tb + ".ff.net.0.proj.bias"))
+            t[tb + ".ff1"] = interleave_geglu(wp, None)[0].contiguous()
+            csi, bi = interleave_geglu(cs[:, None], tt)
+            t[tb + ".ff1.colsum"], t[tb + ".ff1.bias"] = csi[:, 0].contiguous(), bi.contiguous()
+
+        t2d, tt = _sites(cfg)
+        for pfx, _c in t2d:
+            tb = pfx + ".transformer_blocks.0"
+            a1, a2 = tb + ".attn1", tb + ".attn2"
+            fold(a1 + ".qkv", torch.cat([g(a1 + ".to_q.weight"), g(a1 + ".to_k.weight"), g(a1 + ".to_v.weight")]), tb + ".norm1")
+            t[a1 + ".out"] = bf(g(a1 + ".to_out.0.weight"))
+            fold(a2 + ".q", g(a2 + ".to_q.weight"), tb + ".norm2")
+            t[a2 + ".out"] = bf(g(a2 + ".to_out.0.weight"))
+            t[a2 + ".kv_rows"] = bf(torch.cat([g(a2 + ".to_k.weight"), g(a2 + ".to_v.weight")])[None])
+            ff(tb)
+        for pfx, _c, _inner in tt:
+            tb = pfx + ".transformer_blocks.0"
+            for a, norm in ((tb + ".attn1", tb + ".norm1"), (tb + ".attn2", tb + ".norm2")):
+                fold(a + ".qkv", torch.cat([g(a + ".to_q.weight"), g(a + ".to_k.weight"), g(a + ".to_v.weight")]), norm)
+                t[a + ".out"] = bf(g(a + ".to_out.0.weight"))
+            ff(tb)
+        self.t = t
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+
+@torch.no_grad()
+def conditioning(W: I2VWeights, fps, image_latents, image_embeddings, encoder_hidden_states):
+    """the sample- and timestep-independent part of I2VGenXLUNet.forward (fps embedding, context tokens, image-latent
+    features), once per video, stock torch ops in fp32 on the device.  Shapes as the pipeline passes them:
+    fps [B], image_latents [B,4,F,h,w], image_embeddings [B,cross], encoder_hidden_states [B,77,cross]."""
+    cfg, dev = W.cfg, W.device
+    p = {k: v.to(dev, F32) for k, v in W.raw.items()}
+    lin = lambda x, n: F.linear(x, p[n + ".weight"], p[n + ".bias"])
+    B, Cc, Fr, H, Wd = image_latents.shape
+    il = image_latents.to(dev, F32)
+    half = cfg.block_out_channels[0] // 2
+    freqs = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(half, dtype=F32) / half).to(dev)
+    a = fps.to(dev, F32)[:, None] * freqs[None]
+    fps_emb = lin(F.silu(lin(torch.cat([torch.cos(a), torch.sin(a)], -1), "fps_embedding.0")), "fps_embedding.2")
+    n = "image_latents_context_embedding"
+    v = F.silu(F.conv2d(il[:, :, 0], p[n + ".0.weight"], p[n + ".0.bias"], padding=1))
+    v = F.adaptive_avg_pool2d(v, (cfg.ctx_pool, cfg.ctx_pool))
+    v = F.silu(F.conv2d(v, p[n + ".3.weight"], p[n + ".3.bias"], stride=2, padding=1))
+    v = F.conv2d(v, p[n + ".5.weight"], p[n + ".5.bias"], stride=2, padding=1)
+    ctx_img = v.permute(0, 2, 3, 1).reshape(B, -1, cfg.cross_dim)
+    e = lin(F.silu(lin(image_embeddings.to(dev, F32), "context_embedding.0")), "context_embedding.2").view(B, cfg.in_channels, cfg.cross_dim)
+    context = torch.cat([encoder_hidden_states.to(dev, F32), ctx_img, e], dim=1)
+    n = "image_latents_proj_in"
+    x = il.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, H, Wd)
+    x = F.silu(F.conv2d(x, p[n + ".0.weight"], p[n + ".0.bias"], padding=1))
+    x = F.silu(F.conv2d(x, p[n + ".2.weight"], p[n + ".2.bias"], padding=1))
+    x = F.conv2d(x, p[n + ".4.weight"], p[n + ".4.bias"], padding=1)
+    x = x.view(B, Fr, Cc, H, Wd).permute(0, 3, 4, 1, 2).reshape(B * H * Wd, Fr, Cc)
+    n = "image_latents_temporal_encoder"
+    h = F.layer_norm(x, (Cc,), p[n + ".norm1.weight"], p[n + ".norm1.bias"], 1e-5)
+    q = F.linear(h, p[n + ".attn1.to_q.weight"]).view(-1, Fr, 2, Cc).transpose(1, 2)
+    k = F.linear(h, p[n + ".attn1.to_k.weight"]).view(-1, Fr, 2, Cc).transpose(1, 2)
+    vv = F.linear(h, p[n + ".attn1.to_v.weight"]).view(-1, Fr, 2, Cc).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k, vv).transpose(1, 2).reshape(-1, Fr, 2 * Cc)
+    x = x + lin(o, n + ".attn1.to_out.0")
+    x = x + lin(F.gelu(lin(x, n + ".ff.net.0.proj")), n + ".ff.net.2")
+    il_feat = x.view(B, H, Wd, Fr, Cc).permute(0, 4, 3, 1, 2).contiguous()
+    return fps_emb, context, il_feat
+
+
+class _KV:
+    """cross-attention K / V^T of every spatial transformer for the (constant) context, one row per image (= clip x frame)."""
+
+    def __init__(self, W: I2VWeights, context, frames):
+        t2d, _tt = _sites(W.cfg)
+        ctx = context.to(W.device, BF16).contiguous()
+        B, Lk, _ = ctx.shape
+        self.B, self.Lk = B * frames, Lk
+        self.ld = (Lk + 7) // 8 * 8
+        self.k, self.vt = {}, {}
+        for pfx, Cc in t2d:
+            a2 = pfx + ".transformer_blocks.0.attn2"
+            k = torch.empty(B, Lk, Cc, device=W.device, dtype=BF16)
+            vt = torch.zeros(B, Cc, self.ld, device=W.device, dtype=BF16)
+            wkv = W[a2 + ".kv_rows"][0]                            # [2C, cross]; C = 320 is not a multiple of the 128-column
+            ops.gemm(ctx, wkv[:Cc].contiguous(), out=k)            # transposed-region granularity, so K and V^T are two launches
+            ops.gemm(ctx, wkv[Cc:].contiguous(), out_t=vt, n_trans_begin=0)
+            self.k[a2] = k.repeat_interleave(frames, dim=0).contiguous()
+            self.vt[a2] = vt.repeat_interleave(frames, dim=0).contiguous()
+        torch.cuda.synchronize()
+
+
+class I2VPlan(UNetPlan):
+    """pre-recorded forward of the I2VGen-XL UNet for `clips` videos of `frames` latent frames of h x w (CFG: clips = 2).
+    __call__(sample [clips,4,F,h,w], t) -> prediction [clips,4,F,h,w] fp32."""
+
+    def __init__(self, W: I2VWeights, clips: int, frames: int, h: int, w: int, fps_emb, context, il_feat, autotune: bool = True):
+        cfg = W.cfg
+        self.W, self.cfg, self.clips, self.frames, self.h, self.w = W, cfg, clips, frames, h, w
+        self.B = B = clips * frames                     # spatial layers see every frame as one image
+        self.row_sets, self.routed, self._rows_cache = list(range(B)), False, {}
+        self.lib, self.dev = L.load(), W.device
+        dev = self.dev
+        self.ops, self.keep, self.arena = [], [], _Arena(dev)
+        self.flops = self.gemm_flops = 0
+        self.launches = {"gemm": [], "conv": [], "attn": []}
+        self._tunable, self._ln_links, self._vt = [], [], {}
+        self.kv = _KV(W, context, frames)
+        self.x_in = torch.zeros(B, 2 * cfg.in_channels, h, w, device=dev, dtype=F32)
+        self.x_in.view(clips, frames, 2 * cfg.in_channels, h, w)[:, :, cfg.in_channels:] = il_feat.to(dev, F32).permute(0, 2, 1, 3, 4)
+        self.latent = self.x_in                          # (UNetPlan interface name)
+        self.t_dev = torch.zeros(clips, device=dev, dtype=F32)
+        self.eps = torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
+        self.fps_emb = fps_emb.to(dev, F32).contiguous()
+        cmax = max(max(cfg.block_out_channels) * 2, cfg.transformer_in_heads * cfg.head_dim)
+        self._gn_ws = ops.groupnorm_ws(B, cmax, cfg.norm_groups, dev)
+        t2d, tt = _sites(cfg)
+        need = max(((inner + 127) // 128) for _p, _c, inner in tt + [(p_, c_, c_) for p_, c_ in t2d]) * B * h * w * 2
+        self._ln_buf = torch.zeros(need, device=dev, dtype=F32)
+        self._build()
+        self._link_ln()
+        if autotune:
+            self.autotune()
+
+    # ------------------------------------------------------------------ emitters the image UNet did not need
+    def _resnet(self, x, Ci, Co, Hh, Ww, name, emb):
+        """ResnetBlock2D as in the image UNet, except that the time embedding exists once per CLIP ([clips, T]): its
+        projection is added to every frame of the clip through the conv's batch_bias_images."""
+        B, W, A = self.B, self.W, self.arena
+        HW = Hh * Ww
+        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True)
+        temb = torch.empty(self.clips, Co, device=self.dev, dtype=F32)
+        self.keep.append(temb)
+        self._emit(self.lib.tmix_linear_small, emb.data_ptr(), W[name + ".time_emb_proj.weight"].data_ptr(),
+                   W[name + ".time_emb_proj.bias"].data_ptr(), None, temb.data_ptr(), self.clips, Co, self.cfg.time_embed_dim, 1, 0)
+        h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb, bias_images=self.frames)
+        A.put(h1)
+        h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
+        A.put(h2)
+        if Ci != Co:
+            sc = A.get(B, HW, Co)
+            self._gemm(x.view(B * HW, Ci), W[name + ".conv_shortcut.weight"], sc.view(B * HW, Co), bias=W[name + ".conv_shortcut.bias"])
+        else:
+            sc = x
+        out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, residual=sc)
+        A.put(h3)
+        if Ci != Co:
+            A.put(sc)
+        return out
+
+    def _gn_b(self, x, Bn, Cc, HW, name, eps, silu):
+        out = self.arena.get(*x.shape)
+        W = self.W
+        self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+                   W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), Bn, HW, self.cfg.norm_groups, eps, int(silu))
+        return out
+
+    def _conv_t3(self, x, wname, HW, Cc, residual=None):
+        """Conv3d (3,1,1) over the frame axis: x [(clips frames), hw, C] seen as [clips, frames, hw, C]."""
+        out = self.arena.get(self.B, HW, Cc)
+        shp = (self.clips, self.frames, HW, Cc)
+        d = ops.make_conv_desc(x.view(*shp), self.W[wname + ".weight"], out.view(*shp), self.W[wname + ".bias"], None,
+                               None if residual is None else residual, L.CONV_T3)
+        self.keep.append(d)
+        self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
+        fl = 2 * self.B * HW * Cc * 3 * Cc
+        self.flops += fl
+        self.launches["conv"].append((d, fl))
+        self._tunable.append((len(self.ops) - 1, "conv", d))
+        return out
+
+    def _temp_conv(self, x, Cc, HW, name):
+        """diffusers TemporalConvLayer: x + conv4(conv3(conv2(conv1(x)))), each conv = GroupNorm (over the whole clip) + SiLU + Conv3d."""
+        A = self.arena
+        v = x
+        for k, idx in ((1, 2), (2, 3), (3, 3), (4, 3)):
+            gq = self._gn_b(v, self.clips, Cc, self.frames * HW, f"{name}.conv{k}.0", 1e-5, True)
+            if v is not x:
+                A.put(v)
+            v = self._conv_t3(gq, f"{name}.conv{k}.{idx}", HW, Cc, residual=x if k == 4 else None)
+            A.put(gq)
+        return v
+
+    def _tattn(self, h, a, inner, heads, HW, st, st_next):
+        """one self-attention over the frame axis (LayerNorm folded into the fused q/k/v projection)."""
+        A, W, M = self.arena, self.W, self.B * HW
+        qkv = A.get(self.B, HW, 3 * inner)
+        self._gemm(h.view(M, inner), W[a + ".qkv"], qkv.view(M, 3 * inner), bias=W[a + ".qkv.bias"], ln_stats=st, ln_colsum=W[a + ".qkv.colsum"])
+        ao = A.get(self.B, HW, inner)
+        self._emit(self.lib.tmix_temporal_attn, qkv.data_ptr(), 3 * inner, ao.data_ptr(), inner, self.clips, self.frames, HW, heads,
+                   self.cfg.head_dim ** -0.5)
+        self.flops += 4 * self.clips * HW * heads * self.frames * self.frames * 64
+        A.put(qkv)
+        self._gemm(ao.view(M, inner), W[a + ".out"], h.view(M, inner), bias=W[a + ".to_out.0.bias"], residual=h.view(M, inner), row_stats_out=st_next)
+        A.put(ao)
+
+    def _ttemp(self, x, Cc, inner, HW, name):
+        """diffusers TransformerTemporalModel (1 layer, both attentions self over the frames, GEGLU feed-forward)."""
+        A, W, M = self.arena, self.W, self.B * HW
+        heads = inner // self.cfg.head_dim
+        gq = self._gn_b(x, self.clips, Cc, self.frames * HW, name + ".norm", 1e-6, False)
+        h = A.get(self.B, HW, inner)
+        pm = (inner + 127) // 128
+        st = self._ln_buf[:pm * M * 2].view(pm, M, 2)
+        self._gemm(gq.view(M, Cc), W[name + ".proj_in.weight"], h.view(M, inner), bias=W[name + ".proj_in.bias"], row_stats_out=st)
+        A.put(gq)
+        tb = name + ".transformer_blocks.0"
+        self._tattn(h, tb + ".attn1", inner, heads, HW, st, st)
+        self._tattn(h, tb + ".attn2", inner, heads, HW, st, st)
+        f = A.get(M, 4 * inner)
+        self._gemm(h.view(M, inner), W[tb + ".ff1"], f, bias=W[tb + ".ff1.bias"], geglu=True, ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"])
+        self._gemm(f, W[tb + ".ff.net.2.weight"], h.view(M, inner), bias=W[tb + ".ff.net.2.bias"], residual=h.view(M, inner))
+        A.put(f)
+        out = A.get(self.B, HW, Cc)
+        self._gemm(h.view(M, inner), W[name + ".proj_out.weight"], out.view(M, Cc), bias=W[name + ".proj_out.bias"], residual=x.view(M, Cc))
+        A.put(h)
+        return out
+
+    # ------------------------------------------------------------------ whole network (order of I2VGenXLUNet.forward)
+    def _build(self):
+        cfg, W, B, A, lib = self.cfg, self.W, self.B, self.arena, self.lib
+        ch, nb, T = cfg.block_out_channels, len(cfg.block_out_channels), cfg.time_embed_dim
+        C0 = ch[0]
+        nc = self.clips                               # time / fps embeddings exist once per clip
+        tsin = torch.empty(nc, C0, device=self.dev, dtype=F32)
+        thid = torch.empty(nc, T, device=self.dev, dtype=F32)
+        emb = torch.empty(nc, T, device=self.dev, dtype=F32)
+        self.keep += [tsin, thid, emb]
+        self._emit(lib.tmix_timestep_embedding, self.t_dev.data_ptr(), tsin.data_ptr(), nc, C0)
+        self._emit(lib.tmix_linear_small, tsin.data_ptr(), W["time_embedding.linear_1.weight"].data_ptr(),
+                   W["time_embedding.linear_1.bias"].data_ptr(), None, thid.data_ptr(), nc, T, C0, 0, 1)
+        self._emit(lib.tmix_linear_small, thid.data_ptr(), W["time_embedding.linear_2.weight"].data_ptr(),
+                   W["time_embedding.linear_2.bias"].data_ptr(), self.fps_emb.data_ptr(), emb.data_ptr(), nc, T, T, 0, 0)
+        Hh, Ww = self.h, self.w
+        x = A.get(B, Hh * Ww, C0)
+        self._emit(lib.tmix_conv_in, self.x_in.data_ptr(), W["conv_in.weight"].data_ptr(), W["conv_in.bias"].data_ptr(),
+                   x.data_ptr(), B, 2 * cfg.in_channels, Hh, Ww, C0)
+        x2 = self._ttemp(x, C0, cfg.transformer_in_heads * cfg.head_dim, Hh * Ww, "transformer_in")
+        A.put(x)
+        x = x2
+
+        def layer(x, ci, co, pfx, j, attn):
+            y = self._resnet(x, ci, co, Hh, Ww, f"{pfx}.resnets.{j}", emb)
+            y2 = self._temp_conv(y, co, Hh * Ww, f"{pfx}.temp_convs.{j}")
+            A.put(y)
+            if attn:
+                y = self._t2d(y2, co, Hh, Ww, f"{pfx}.attentions.{j}", 1)
+                A.put(y2)
+                y2 = self._ttemp(y, co, co, Hh * Ww, f"{pfx}.temp_attentions.{j}")
+                A.put(y)
+            return y2
+
+        skips = [(x, C0)]
+        ci = C0
+        for bi, co in enumerate(ch):
+            for j in range(cfg.layers_per_block):
+                x = layer(x, ci, co, f"down_blocks.{bi}", j, cfg.attn_levels[bi])
+                ci = co
+                skips.append((x, co))
+            if bi < nb - 1:
+                x = self._conv(x, f"down_blocks.{bi}.downsamplers.0.conv", Hh, Ww, co, co, mode=L.CONV_S2)
+                Hh, Ww = Hh // 2, Ww // 2
+                skips.append((x, co))
+        cm = ch[-1]
+        y = self._resnet(x, cm, cm, Hh, Ww, "mid_block.resnets.0", emb)
+        y2 = self._temp_conv(y, cm, Hh * Ww, "mid_block.temp_convs.0"); A.put(y)
+        y = self._t2d(y2, cm, Hh, Ww, "mid_block.attentions.0", 1); A.put(y2)
+        y2 = self._ttemp(y, cm, cm, Hh * Ww, "mid_block.temp_attentions.0"); A.put(y)
+        y = self._resnet(y2, cm, cm, Hh, Ww, "mid_block.resnets.1", emb); A.put(y2)
+        x = self._temp_conv(y, cm, Hh * Ww, "mid_block.temp_convs.1"); A.put(y)
+        for ui in range(nb):
+            bi = nb - 1 - ui
+            co = ch[bi]
+            for j in range(cfg.layers_per_block + 1):
+                sk, cs = skips.pop()
+                xc = self._cat(x, ci, sk, cs, Hh * Ww)
+                A.put(x, sk)
+                x = layer(xc, ci + cs, co, f"up_blocks.{ui}", j, cfg.attn_levels[bi])
+                A.put(xc)
+                ci = co
+            if ui < nb - 1:
+                x2 = self._conv(x, f"up_blocks.{ui}.upsamplers.0.conv", Hh, Ww, co, co, mode=L.CONV_UP2)
+                A.put(x)
+                x = x2
+                Hh, Ww = Hh * 2, Ww * 2
+        y = self._gn(x, C0, Hh * Ww, "conv_norm_out", 1e-5, True)
+        A.put(x)
+        self._emit(lib.tmix_conv_out, y.data_ptr(), W["conv_out.weight"].data_ptr(), W["conv_out.bias"].data_ptr(),
+                   self.eps.data_ptr(), B, C0, Hh, Ww, cfg.out_channels)
+        self.ops = [(fn, tuple(a)) for fn, a in self.ops]
+
+    def __call__(self, sample, t):
+        cfg = self.cfg
+        xin = self.x_in.view(self.clips, self.frames, 2 * cfg.in_channels, self.h, self.w)
+        xin[:, :, :cfg.in_channels] = sample.to(self.dev, F32).permute(0, 2, 1, 3, 4)
+        self.t_dev.fill_(float(t))
+        self.run()
+        return self.eps.view(self.clips, self.frames, cfg.out_channels, self.h, self.w).permute(0, 2, 1, 3, 4)

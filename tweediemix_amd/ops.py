@@ -141,7 +141,7 @@ def gemm(a, w, out=None, **kw):
     return out if out is not None else kw.get("out_f32")
 
 
-def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0):
+def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0, bias_images=1):
     """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous ([Cout,3,Cin] for the temporal CONV_T3,
     where x is [clips, frames, h*w, Cin])."""
     B, H, W, Cin = x.shape
@@ -153,6 +153,7 @@ def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.
     d.bias, d.batch_bias, d.residual = _p(bias), _p(batch_bias), _p(residual)
     d.B, d.H, d.W, d.Cin, d.Cout, d.mode = B, H, W, Cin, Cout, mode
     d.tile_cfg = tile_cfg
+    d.batch_bias_images = bias_images      # consecutive images sharing one batch_bias row (video: frames of a clip)
     return d
 
 

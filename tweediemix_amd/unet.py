@@ -422,11 +422,11 @@ class UNetPlan:
         self._tunable.append((len(self.ops) - 1, "gemm", d))
         return out
 
-    def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None):
+    def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None, bias_images=1):
         Ho, Wo = ops.conv_out_hw(Hh, Ww, mode)
         out = self.arena.get(self.B, Ho * Wo, Cout)
         d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Cin), self.W[wname + ".weight"], out.view(self.B, Ho, Wo, Cout),
-                               self.W[wname + ".bias"], batch_bias, residual, mode)
+                               self.W[wname + ".bias"], batch_bias, residual, mode, bias_images=bias_images)
         self.keep.append(d)
         self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
         fl = 2 * self.B * Ho * Wo * Cout * 9 * Cin
