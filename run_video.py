@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's run_video.py (I2VGen-XL image-to-video from the fused image, BASELINE config #5).
+
+The reference script hard-codes its inputs and pulls `ali-vilab/i2vgen-xl` from the hub; here the same settings are flags
+with the reference's values as defaults, and the model comes from local files:
+
+  --i2v_path           diffusers-layout I2VGen-XL folder: unet/diffusion_pytorch_model[.fp16].safetensors (+ vae/ for frames)
+  --conditioning_path  torch file with what the pipeline computes before its loop (video_gen/pipeline_i2vgen_xl.py:604-639):
+                       {'prompt_embeds': [2,77,1024] (negative row first), 'image_embeddings': [2,1024] (zeros row first),
+                        'image_latents': [2,4,F,h,w]}  -- the OpenCLIP ViT-H text / vision towers and the VAE ENCODER that
+                       produce them are not rebuilt in this repository yet
+  --alphas_cumprod     .npy with the checkpoint scheduler's 1000-entry table (else: cosine schedule with zero terminal SNR)
+  --synthetic          random-init network and conditioning of the real shapes (no checkpoints exist offline)
+
+Per step: native UNet forward on the CFG pair (tweediemix_amd/i2vgen.py) with the first-frame feature injection of
+video_gen/utils_attn.py:389-474 for the first int(steps * injection_timestep) steps, then the fused CFG / v-prediction /
+DDIM update (tmix_vpred_step).  Output: output_i2v_seed_<seed>.latent.pt, plus output_i2v_seed_<seed>.gif with --vae_path."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # the reference script's constants (run_video.py:7-38)
+    p.add_argument("--image_path", default="test_out/photo of a cat and a dog running, mountain background_3821.png")
+    p.add_argument("--prompt", default="A cat and a dog running, mountain background")
+    p.add_argument("--negative_prompt", default="Distorted, discontinuous, Ugly, blurry, low resolution, motionless, static, disfigured, "
+                                                "disconnected limbs, Ugly faces, incomplete arms")
+    p.add_argument("--seed", type=int, default=6425)
+    p.add_argument("--num_inference_steps", type=int, default=50)
+    p.add_argument("--guidance_scale", type=float, default=9.0)
+    p.add_argument("--height", type=int, default=512)
+    p.add_argument("--width", type=int, default=512)
+    p.add_argument("--target_fps", type=int, default=8)
+    p.add_argument("--num_frames", type=int, default=16)
+    p.add_argument("--injection_timestep", type=float, default=0.02)
+    p.add_argument("--interp_ratio", type=float, default=0.7)
+    # local inputs
+    p.add_argument("--i2v_path", default="")
+    p.add_argument("--conditioning_path", default="")
+    p.add_argument("--alphas_cumprod", default="")
+    p.add_argument("--vae_path", default="")
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--tiny", action="store_true", help="tiny network (smoke tests)")
+    p.add_argument("--no_graphs", action="store_true")
+    return p
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    from tweediemix_amd import i2vgen as I, ops, video as V
+    cfg = I.TINY if opt.tiny else I.FULL
+    h, w, Fr = opt.height // 8, opt.width // 8, opt.num_frames
+    if Fr != 16:
+        print("note: the reference's injection hook hard-codes 16 frames (video_gen/utils_attn.py:439)")
+    gen = torch.Generator().manual_seed(opt.seed)
+    if opt.synthetic:
+        from tweediemix_amd.weights import synthetic_i2vgen_state_dict
+        sd = synthetic_i2vgen_state_dict(cfg)
+        cond = {"prompt_embeds": torch.randn(2, 77, cfg.cross_dim, generator=gen), "image_embeddings": torch.randn(2, cfg.cross_dim, generator=gen),
+                "image_latents": torch.randn(2, 4, Fr, h, w, generator=gen)}
+    else:
+        if not (opt.i2v_path and opt.conditioning_path):
+            sys.exit("need --i2v_path and --conditioning_path (or --synthetic); there is no hub download here")
+        from fusion_generation.fusion_sampling import find_weights, load_state_dict
+        sd = load_state_dict(find_weights(os.path.join(opt.i2v_path, "unet"), "diffusion_pytorch_model"))
+        cond = torch.load(opt.conditioning_path, map_location="cpu")
+    Wt = I.I2VWeights(cfg, sd)
+    fps = torch.tensor([float(opt.target_fps)] * 2)
+    fe, ctx, ilf = I.conditioning(Wt, fps, cond["image_latents"], cond["image_embeddings"], cond["prompt_embeds"])
+    plan = I.I2VPlan(Wt, 2, Fr, h, w, fe, ctx, ilf, interp=opt.interp_ratio)
+    if opt.alphas_cumprod:
+        acp = np.load(opt.alphas_cumprod).astype(np.float32)
+    else:                                   # stand-in table: squaredcos_cap_v2 betas rescaled to zero terminal SNR
+        ab = np.cos((np.arange(1001) / 1000 + 0.008) / 1.008 * np.pi / 2) ** 2
+        betas = np.minimum(1 - ab[1:] / ab[:-1], 0.999)
+        s = np.sqrt(np.cumprod(1 - betas))
+        s = (s - s[-1]) * s[0] / (s[0] - s[-1])
+        acp = (s ** 2).astype(np.float32)
+    sch = V.VideoSchedule(acp, opt.num_inference_steps)
+    inj = V.FeatureInjector(sch.injection_schedule(opt.injection_timestep), opt.interp_ratio, clips=2, frames=Fr)
+    x = torch.randn(1, 4, Fr, h, w, generator=gen).cuda()          # latents * init_noise_sigma (= 1 for DDIM)
+    graphs = {}
+
+    def unet(xin, t):                                               # one recorded forward per injection state, replayed as a hipGraph
+        xv = plan.x_in.view(2, Fr, 2 * cfg.in_channels, h, w)
+        xv[:, :, :cfg.in_channels] = xin.permute(0, 2, 1, 3, 4)
+        plan.t_dev.fill_(float(t))
+        if opt.no_graphs:
+            plan.run()
+        else:
+            g = graphs.get(plan.inject)
+            if g is None:
+                plan.run(); torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    plan.run()
+                graphs[plan.inject] = g
+            g.replay()
+        return plan.eps.view(2, Fr, cfg.out_channels, h, w).permute(0, 2, 1, 3, 4).contiguous()
+
+    unet.plan = plan
+    lat = V.sample_loop(unet, x, sch, opt.guidance_scale, inj)
+    out = f"output_i2v_seed_{opt.seed}.latent.pt"
+    torch.save(lat.cpu(), out)
+    print("saved", out)
+    if opt.vae_path:
+        import json
+        from PIL import Image
+        from fusion_generation.fusion_sampling import find_weights, load_state_dict
+        from tweediemix_amd import vae as VA
+        vcfg = VA.FULL
+        if os.path.isdir(opt.vae_path) and os.path.exists(os.path.join(opt.vae_path, "config.json")):
+            j = json.load(open(os.path.join(opt.vae_path, "config.json")))
+            vcfg = dict(block_out_channels=tuple(j["block_out_channels"]), layers_per_block=j.get("layers_per_block", 2),
+                        latent_channels=j.get("latent_channels", 4), out_channels=j.get("out_channels", 3), groups=j.get("norm_num_groups", 32))
+        dec = VA.VAEDecoderPlan(vcfg, load_state_dict(find_weights(opt.vae_path, "diffusion_pytorch_model")), 1, h, w, 1 / 0.18215, "cuda")
+        frames = []
+        for f in range(Fr):                                         # pipeline decode_latents: 1/scaling_factor, per frame
+            img = dec(lat[:, :, f].contiguous())[0].clamp(0, 1)
+            frames.append(Image.fromarray((img.permute(1, 2, 0).float().cpu().numpy() * 255).round().astype("uint8")))
+        gif = f"output_i2v_seed_{opt.seed}.gif"
+        frames[0].save(gif, save_all=True, append_images=frames[1:], duration=1000 // opt.target_fps, loop=0)
+        print("saved", gif)
+    return lat
+
+
+if __name__ == "__main__":
+    main()

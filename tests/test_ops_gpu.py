@@ -350,3 +350,19 @@ def test_temporal_attention(ops, frames):
     ref = F.scaled_dot_product_attention(x[0], x[1], x[2])                               # over frames
     ref = ref.permute(0, 3, 1, 2, 4).reshape(clips * frames, hw, C)
     close(out, ref, rtol=2 ** -6, atol_frac=4e-3)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7])
+def test_gemm_transposed_region_on_a_128_boundary(ops, cfg):
+    """q/k/v of a 320-channel layer (I2VGen-XL level 0): the transposed V region starts at column 640, a multiple of 128 but
+    not of 256 -- the 256-wide tilings must fall back instead of writing V columns into the row-major output."""
+    S, Cc = 200, 320
+    x = rnd(2, S, Cc, seed=97)
+    wt = rnd(3 * Cc, Cc, seed=98, scale=Cc ** -0.5)
+    vt = torch.zeros(2, Cc, 200, device="cuda", dtype=BF)
+    guard = torch.full((2, S + 8, 2 * Cc), 7.0, device="cuda", dtype=BF)
+    qk = ops.gemm(x, wt, out=guard[:, :S], out_t=vt, n_trans_begin=2 * Cc, tile_cfg=cfg)
+    ref = x.float() @ wt.float().T
+    close(qk, ref[:, :, :2 * Cc], rtol=2 ** -6, atol_frac=4e-3)
+    close(vt, ref[:, :, 2 * Cc:].transpose(1, 2), rtol=2 ** -6, atol_frac=4e-3)
+    assert float(guard[:, S:].float().min()) == 7.0 and float(guard[:, S:].float().max()) == 7.0

@@ -586,6 +586,7 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
     if (p.n_trans_begin >= 0) {                                                // transposed stores need square wave tiles
         if (cfg == 4 || cfg == 5 || cfg == 7) cfg = 2;
+        if (cfg == 6 && (p.n_trans_begin % 256)) cfg = 2;                     // the boundary must fall on a tile edge (N = 3 x 320: 640)
         if (cfg == 8 || cfg == 11) cfg = 9;
     }
     switch (cfg) {

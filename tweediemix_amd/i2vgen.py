@@ -184,12 +184,33 @@ class _KV:
         torch.cuda.synchronize()
 
 
+class _Inject:
+    """first-frame feature injection of the reference's patched ResnetBlock2D.forward (video_gen/utils_attn.py:433-455) as an op
+    of the recorded forward: a no-op unless the plan's `inject` flag is up (the loop raises it for the scheduled timesteps)."""
+    __name__ = "tmix_frame_inject"
+
+    def __init__(self, plan, buf, per_frame, hard):
+        self.plan, self.ptr, self.per_frame, self.hard = plan, buf.data_ptr(), per_frame, hard
+
+    def __call__(self, st):
+        p = self.plan
+        if not p.inject:
+            return 0
+        a = 0.0 if self.hard else float(torch.tensor(p.interp, dtype=torch.float32))
+        b = 0.0 if self.hard else float(torch.tensor(1.0 - float(p.interp), dtype=torch.float32))
+        return p.lib.tmix_frame_inject(self.ptr, L.BF16, p.clips, p.frames, self.per_frame, int(self.hard), a, b, st)
+
+
 class I2VPlan(UNetPlan):
     """pre-recorded forward of the I2VGen-XL UNet for `clips` videos of `frames` latent frames of h x w (CFG: clips = 2).
     __call__(sample [clips,4,F,h,w], t) -> prediction [clips,4,F,h,w] fp32."""
 
-    def __init__(self, W: I2VWeights, clips: int, frames: int, h: int, w: int, fps_emb, context, il_feat, autotune: bool = True):
+    INJECT_SITES = {"mid_block.resnets.0": True, "mid_block.resnets.1": True, "up_blocks.1.resnets.0": False}   # site -> hard copy?
+
+    def __init__(self, W: I2VWeights, clips: int, frames: int, h: int, w: int, fps_emb, context, il_feat, autotune: bool = True,
+                 interp: float = 0.7):
         cfg = W.cfg
+        self.inject, self.interp = False, interp         # raised per step by the sampling loop (FeatureInjector schedule)
         self.W, self.cfg, self.clips, self.frames, self.h, self.w = W, cfg, clips, frames, h, w
         self.B = B = clips * frames                     # spatial layers see every frame as one image
         self.row_sets, self.routed, self._rows_cache = list(range(B)), False, {}
@@ -248,6 +269,10 @@ class I2VPlan(UNetPlan):
         self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
                    W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), Bn, HW, self.cfg.norm_groups, eps, int(silu))
         return out
+
+    def _inject_site(self, buf, site, per_frame):
+        if site in self.INJECT_SITES:
+            self.ops.append((_Inject(self, buf, per_frame, self.INJECT_SITES[site]), ()))
 
     def _conv_t3(self, x, wname, HW, Cc, residual=None):
         """Conv3d (3,1,1) over the frame axis: x [(clips frames), hw, C] seen as [clips, frames, hw, C]."""
@@ -335,6 +360,7 @@ class I2VPlan(UNetPlan):
 
         def layer(x, ci, co, pfx, j, attn):
             y = self._resnet(x, ci, co, Hh, Ww, f"{pfx}.resnets.{j}", emb)
+            self._inject_site(y, f"{pfx}.resnets.{j}", Hh * Ww * co)
             y2 = self._temp_conv(y, co, Hh * Ww, f"{pfx}.temp_convs.{j}")
             A.put(y)
             if attn:
@@ -357,10 +383,12 @@ class I2VPlan(UNetPlan):
                 skips.append((x, co))
         cm = ch[-1]
         y = self._resnet(x, cm, cm, Hh, Ww, "mid_block.resnets.0", emb)
+        self._inject_site(y, "mid_block.resnets.0", Hh * Ww * cm)
         y2 = self._temp_conv(y, cm, Hh * Ww, "mid_block.temp_convs.0"); A.put(y)
         y = self._t2d(y2, cm, Hh, Ww, "mid_block.attentions.0", 1); A.put(y2)
         y2 = self._ttemp(y, cm, cm, Hh * Ww, "mid_block.temp_attentions.0"); A.put(y)
         y = self._resnet(y2, cm, cm, Hh, Ww, "mid_block.resnets.1", emb); A.put(y2)
+        self._inject_site(y, "mid_block.resnets.1", Hh * Ww * cm)
         x = self._temp_conv(y, cm, Hh * Ww, "mid_block.temp_convs.1"); A.put(y)
         for ui in range(nb):
             bi = nb - 1 - ui

@@ -66,6 +66,9 @@ def sample_loop(unet, latents: torch.Tensor, schedule: VideoSchedule, guidance_s
     for t in schedule.timesteps:
         if injector is not None:
             injector.register_time(t)
+            plan = getattr(unet, "plan", None)             # a native I2VPlan carries the injection as ops of its forward
+            if plan is not None:
+                plan.inject, plan.interp = injection_active(int(t), injector.schedule), injector.interp
         v = unet(torch.cat([x, x]), int(t)).contiguous()
         x = ops.vpred_step(x, v, guidance_scale, schedule.alpha(int(t)), schedule.alpha(int(t) - schedule.skip))
     return x

@@ -192,3 +192,111 @@ def synthetic_clip_state_dict(d: int, layers: int, inter: int, vocab: int = 4940
     if proj:
         sd["text_projection.weight"] = rn(proj, d, std=d ** -0.5)
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# I2VGen-XL UNet (BASELINE config #5): parameter inventory and random-init weights in diffusers' key scheme
+def i2vgen_param_shapes(cfg) -> dict:
+    s = {}
+    ch, T, ic, cd = cfg.block_out_channels, cfg.time_embed_dim, cfg.in_channels, cfg.cross_dim
+    """parameter inventory of diffusers' I2VGenXLUNet (structure documented in tweediemix_amd/i2vgen.py; 1,420,469,224 parameters)"""
+
+    def conv(n, i, o, k=3):
+        s[n + ".weight"], s[n + ".bias"] = (o, i, k, k), (o,)
+
+    def lin(n, i, o, bias=True):
+        s[n + ".weight"] = (o, i)
+        if bias:
+            s[n + ".bias"] = (o,)
+
+    def vec2(n, c):
+        s[n + ".weight"], s[n + ".bias"] = (c,), (c,)
+
+    def resnet(n, ci, co):
+        vec2(n + ".norm1", ci); conv(n + ".conv1", ci, co); lin(n + ".time_emb_proj", T, co)
+        vec2(n + ".norm2", co); conv(n + ".conv2", co, co)
+        if ci != co:
+            conv(n + ".conv_shortcut", ci, co, 1)
+
+    def temp_conv(n, c):
+        for k, idx in ((1, 2), (2, 3), (3, 3), (4, 3)):
+            vec2(f"{n}.conv{k}.0", c)
+            s[f"{n}.conv{k}.{idx}.weight"], s[f"{n}.conv{k}.{idx}.bias"] = (c, c, 3, 1, 1), (c,)
+
+    def block(n, dim, cross):
+        vec2(n + ".norm1", dim); vec2(n + ".norm2", dim); vec2(n + ".norm3", dim)
+        for a, kd in (("attn1", dim), ("attn2", cross)):
+            lin(f"{n}.{a}.to_q", dim, dim, False); lin(f"{n}.{a}.to_k", kd, dim, False); lin(f"{n}.{a}.to_v", kd, dim, False)
+            lin(f"{n}.{a}.to_out.0", dim, dim)
+        lin(n + ".ff.net.0.proj", dim, 8 * dim); lin(n + ".ff.net.2", 4 * dim, dim)
+
+    def t2d(n, c):
+        vec2(n + ".norm", c); lin(n + ".proj_in", c, c); block(n + ".transformer_blocks.0", c, cd); lin(n + ".proj_out", c, c)
+
+    def ttemp(n, c, inner):
+        vec2(n + ".norm", c); lin(n + ".proj_in", c, inner); block(n + ".transformer_blocks.0", inner, inner); lin(n + ".proj_out", inner, c)
+
+    conv("conv_in", 2 * ic, ch[0])
+    ttemp("transformer_in", ch[0], cfg.transformer_in_heads * cfg.head_dim)
+    conv("image_latents_proj_in.0", 4, ic * 4); conv("image_latents_proj_in.2", ic * 4, ic * 4); conv("image_latents_proj_in.4", ic * 4, ic)
+    e = "image_latents_temporal_encoder"
+    vec2(e + ".norm1", ic)
+    lin(e + ".attn1.to_q", ic, 2 * ic, False); lin(e + ".attn1.to_k", ic, 2 * ic, False); lin(e + ".attn1.to_v", ic, 2 * ic, False)
+    lin(e + ".attn1.to_out.0", 2 * ic, ic)
+    lin(e + ".ff.net.0.proj", ic, ic * 4); lin(e + ".ff.net.2", ic * 4, ic)
+    conv("image_latents_context_embedding.0", 4, ic * 8); conv("image_latents_context_embedding.3", ic * 8, ic * 16)
+    conv("image_latents_context_embedding.5", ic * 16, cd)
+    lin("time_embedding.linear_1", ch[0], T); lin("time_embedding.linear_2", T, T)
+    lin("context_embedding.0", cd, T); lin("context_embedding.2", T, cd * ic)
+    lin("fps_embedding.0", ch[0], T); lin("fps_embedding.2", T, T)
+    nb = len(ch)
+    ci = ch[0]
+    skips = [ch[0]]
+    for bi, co in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            resnet(f"down_blocks.{bi}.resnets.{j}", ci, co); temp_conv(f"down_blocks.{bi}.temp_convs.{j}", co)
+            if cfg.attn_levels[bi]:
+                t2d(f"down_blocks.{bi}.attentions.{j}", co); ttemp(f"down_blocks.{bi}.temp_attentions.{j}", co, co)
+            ci = co
+            skips.append(co)
+        if bi < nb - 1:
+            conv(f"down_blocks.{bi}.downsamplers.0.conv", co, co)
+            skips.append(co)
+    cm = ch[-1]
+    resnet("mid_block.resnets.0", cm, cm); temp_conv("mid_block.temp_convs.0", cm)
+    t2d("mid_block.attentions.0", cm); ttemp("mid_block.temp_attentions.0", cm, cm)
+    resnet("mid_block.resnets.1", cm, cm); temp_conv("mid_block.temp_convs.1", cm)
+    for ui in range(nb):
+        bi = nb - 1 - ui
+        co = ch[bi]
+        for j in range(cfg.layers_per_block + 1):
+            cs = skips.pop()
+            resnet(f"up_blocks.{ui}.resnets.{j}", ci + cs, co); temp_conv(f"up_blocks.{ui}.temp_convs.{j}", co)
+            if cfg.attn_levels[bi]:
+                t2d(f"up_blocks.{ui}.attentions.{j}", co); ttemp(f"up_blocks.{ui}.temp_attentions.{j}", co, co)
+            ci = co
+        if ui < nb - 1:
+            conv(f"up_blocks.{ui}.upsamplers.0.conv", co, co)
+    vec2("conv_norm_out", ch[0]); conv("conv_out", ch[0], cfg.out_channels)
+    return s
+
+
+def synthetic_i2vgen_state_dict(cfg, seed=99, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shp in i2vgen_param_shapes(cfg).items():
+        if name.endswith(".bias"):
+            v = torch.randn(shp, generator=g) * 0.02
+        elif len(shp) == 1:
+            v = 1 + torch.randn(shp, generator=g) * 0.05
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            v = torch.randn(shp, generator=g) * fan_in ** -0.5
+            if name.endswith("conv4.3.weight"):
+                v = v * 0.3                                   # (zero-init in diffusers; small but non-zero so tests exercise it)
+        sd[name] = v.to(dtype)
+    return sd
+
+
