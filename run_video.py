@@ -6,9 +6,10 @@ with the reference's values as defaults, and the model comes from local files:
 
   --i2v_path           diffusers-layout I2VGen-XL folder: unet/diffusion_pytorch_model[.fp16].safetensors (+ vae/ for frames)
   --conditioning_path  torch file with what the pipeline computes before its loop (video_gen/pipeline_i2vgen_xl.py:604-639):
-                       {'prompt_embeds': [2,77,1024] (negative row first), 'image_embeddings': [2,1024] (zeros row first),
-                        'image_latents': [2,4,F,h,w]}  -- the OpenCLIP ViT-H text / vision towers and the VAE ENCODER that
-                       produce them are not rebuilt in this repository yet
+                       {'image_embeddings': [2,1024] (zeros row first), 'image_latents': [2,4,F,h,w], optionally
+                        'prompt_embeds': [2,77,1024] (negative row first)}.  Without prompt_embeds the text half runs natively
+                       from <i2v_path>/tokenizer + text_encoder (tweediemix_amd/text.py); the ViT-H VISION tower (head size 80)
+                       and the VAE ENCODER behind the two image tensors are not rebuilt in this repository yet
   --alphas_cumprod     .npy with the checkpoint scheduler's 1000-entry table (else: cosine schedule with zero terminal SNR)
   --synthetic          random-init network and conditioning of the real shapes (no checkpoints exist offline)
 
@@ -73,6 +74,11 @@ def main(argv=None):
         from fusion_generation.fusion_sampling import find_weights, load_state_dict
         sd = load_state_dict(find_weights(os.path.join(opt.i2v_path, "unet"), "diffusion_pytorch_model"))
         cond = torch.load(opt.conditioning_path, map_location="cpu")
+        if "prompt_embeds" not in cond:      # text half natively: tokenizer/ + text_encoder/ of the checkpoint (encode_prompt, CFG order)
+            from tweediemix_amd import text as T
+            tok = T.ClipBPETokenizer.from_pretrained(os.path.join(opt.i2v_path, "tokenizer"))
+            enc = T.load_text_tower(os.path.join(opt.i2v_path, "text_encoder"))
+            cond["prompt_embeds"] = enc.last_hidden_state(tok([opt.negative_prompt, opt.prompt])).float().cpu()
     Wt = I.I2VWeights(cfg, sd)
     fps = torch.tensor([float(opt.target_fps)] * 2)
     fe, ctx, ilf = I.conditioning(Wt, fps, cond["image_latents"], cond["image_embeddings"], cond["prompt_embeds"])

@@ -35,6 +35,7 @@ def test_text_tower_matches_oracle(name, golden_dir):
     assert rel(hs, o["hidden_states"][-2]) < 1e-2, rel(hs, o["hidden_states"][-2])
     assert rel(pooled, want_pooled) < 2e-2, rel(pooled, want_pooled)
     assert rel(hs, torch.from_numpy(z[name + ".hs_m2"])) < 2e-2            # and against the transformers vectors directly
+    assert rel(enc.last_hidden_state(ids), torch.from_numpy(z[name + ".last"])) < 2e-2     # text_encoder(ids)[0] (video pipeline)
     assert rel(pooled, torch.from_numpy(z[name + ".pooled"])) < 3e-2
 
 

@@ -89,6 +89,17 @@ class ClipTextEncoder:
         return ops.gemm(h, lw["fc2"], bias=lw["fc2_b"], residual=x)
 
     @torch.no_grad()
+    def last_hidden_state(self, input_ids: torch.Tensor):
+        """[B,S,d] bf16 output of the full tower WITH the final LayerNorm: `text_encoder(ids)[0]`, what the I2VGen-XL pipeline
+        feeds its UNet (video_gen/pipeline_i2vgen_xl.py encode_prompt) -- the SDXL samplers use hidden_states[-2] instead."""
+        ids = input_ids.to(self.dev).long()
+        B, S = ids.shape
+        x = (self.tok[ids] + self.pos[:S][None]).to(BF16).reshape(B * S, self.d).contiguous()
+        for lw in self.layers:
+            x = self._layer(x, lw, B, S)
+        return ops.layernorm(x, self.final_ln[0], self.final_ln[1], self.eps).view(B, S, self.d)
+
+    @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, need_pooled: bool = True):
         """input_ids [B,S] -> (hidden_states[-2] [B,S,d] bf16, pooled [B,proj_dim or d] fp32 or None)."""
         ids = input_ids.to(self.dev).long()
