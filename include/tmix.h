@@ -126,7 +126,9 @@ int tmix_gemm_stats_parts(int N, int tile_cfg);
  */
 /* TMIX_CONV_T3: temporal convolution, kernel (3,1,1) with padding (1,0,0) over the FIRST spatial axis -- X is
  * [clips][frames][h*w][Cin] and Wt [Cout][3][Cin] (diffusers TemporalConvLayer's Conv3d of the I2VGen-XL UNet, config #5). */
-enum { TMIX_CONV_S1 = 0, TMIX_CONV_S2 = 1, TMIX_CONV_UP2 = 2, TMIX_CONV_T3 = 3 };
+/* TMIX_CONV_S2A: stride 2 with the zero padding on the right / bottom edge only (diffusers Downsample2D(padding=0) of the VAE ENCODER:
+ * F.pad(x, (0,1,0,1)) then a stride-2 conv), out[y][x] = sum w[ky][kx] in[2y+ky][2x+kx]. */
+enum { TMIX_CONV_S1 = 0, TMIX_CONV_S2 = 1, TMIX_CONV_UP2 = 2, TMIX_CONV_T3 = 3, TMIX_CONV_S2A = 4 };
 typedef struct {
     const void* X;   /* bf16 [B][H][W][Cin]                                   */
     const void* Wt;  /* bf16 [Cout][3][3][Cin]  ([Cout][3][Cin] for T3)       */
@@ -190,6 +192,10 @@ int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64
  * S is a stack of [seq][cols] score blocks; row r sees columns <= r % seq, every other column (padding included) gets 0. */
 int tmix_softmax_rows_causal(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, float scale,
                              int seq, void* stream);
+/* padded variant (CLIP vision tower of the video pipeline: 257 tokens in rows padded to a multiple of the GEMM K-tile):
+ * columns >= valid get probability 0. */
+int tmix_softmax_rows_masked(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, int valid, float scale,
+                             void* stream);
 /* temporal self-attention over the frame axis (diffusers TransformerTemporalModel of the I2VGen-XL UNet, BASELINE config #5;
  * the reference drives it through video_gen/pipeline_i2vgen_xl.py:688-697): QKV bf16 [(clips*frames)][hw][ld] with columns
  * [0,C) = Q, [C,2C) = K, [2C,3C) = V, C = heads*64; every (clip, pixel, head) attends over its <= 16 frames;

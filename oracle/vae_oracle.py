@@ -98,3 +98,25 @@ class VAEDecoderOracle:
         x = F.silu(self._gn(x, "decoder.conv_norm_out"))
         img = self._conv(x, "decoder.conv_out", padding=1)
         return (img / 2 + 0.5).clamp(0, 1)
+
+    @torch.no_grad()
+    def encode(self, image):
+        """AutoencoderKL.encode up to the diagonal Gaussian's parameters: image [B,3,H,W] in [-1,1] -> (mean, logvar) [B,4,H/8,W/8]
+        (diffusers Encoder: conv_in, DownEncoderBlock2D x4 with Downsample2D(padding=0) = F.pad (0,1,0,1) + stride-2 conv, mid block,
+        conv_norm_out + SiLU + conv_out, then quant_conv; DiagonalGaussianDistribution clamps logvar to [-30, 20]).  Unpinned like
+        decode (no diffusers here); the inventory has the published 34,163,592 encoder parameters."""
+        cfg = self.cfg
+        x = self._conv(image.float(), "encoder.conv_in", padding=1)
+        nb = len(cfg["block_out_channels"])
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"]):
+                x = self._resnet(x, f"encoder.down_blocks.{i}.resnets.{j}")
+            if i < nb - 1:
+                x = self._conv(F.pad(x, (0, 1, 0, 1)), f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2)
+        x = self._resnet(x, "encoder.mid_block.resnets.0")
+        x = self._attn(x, "encoder.mid_block.attentions.0")
+        x = self._resnet(x, "encoder.mid_block.resnets.1")
+        x = self._conv(F.silu(self._gn(x, "encoder.conv_norm_out")), "encoder.conv_out", padding=1)
+        m = self._conv(x, "quant_conv")
+        lc = cfg["latent_channels"]
+        return m[:, :lc], m[:, lc:].clamp(-30.0, 20.0)

@@ -188,3 +188,16 @@ def test_video_step_and_injection_match_reference_vectors(golden_dir):
                     assert np.array_equal(got, z[k + ".out"]), k
         finally:
             O.CPU_SCALAR_TENSOR_SEMANTICS = False
+
+
+def test_clip_vision_oracle_matches_transformers_vectors(golden_dir):
+    """oracle/clip_oracle.py clip_vision_forward against transformers' CLIPVisionModelWithProjection (tests/golden/clip_vision.npz)."""
+    import torch
+    from oracle import clip_oracle as CO
+    z = np.load(os.path.join(golden_dir, "clip_vision.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("sd.")}
+    heads, patch = [int(v) for v in z["meta"]]
+    o = CO.clip_vision_forward(sd, torch.from_numpy(z["pixel_values"]), heads, patch)
+    torch.testing.assert_close(o["image_embeds"], torch.from_numpy(z["image_embeds"]), rtol=1e-4, atol=3e-5)
+    # transformers returns the hidden state BEFORE post_layernorm as last_hidden_state
+    torch.testing.assert_close(o["last_hidden_state"], torch.from_numpy(z["last_hidden_state"]), rtol=1e-4, atol=3e-5)

@@ -89,3 +89,21 @@ def test_full_size_towers_match_oracle(tower):
     want = o["text_embeds"] if proj else o["pooler_output"]
     assert rel(hs, o["hidden_states"][-2]) < 2e-2, rel(hs, o["hidden_states"][-2])
     assert rel(pooled, want) < 3e-2, rel(pooled, want)
+
+
+def test_vision_tower_matches_oracle_and_transformers_vectors(golden_dir):
+    """CLIP image tower with the ViT-H head size (80, zero-padded to 128 for the score GEMM) against oracle/clip_oracle.py and the
+    transformers vectors of tests/golden/clip_vision.npz."""
+    from tweediemix_amd import text as T
+    from oracle import clip_oracle as CO
+    z = np.load(os.path.join(golden_dir, "clip_vision.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("sd.")}
+    heads, patch = [int(v) for v in z["meta"]]
+    x = torch.from_numpy(z["pixel_values"])
+    enc = T.ClipVisionEncoder(sd, heads, patch)
+    got = enc(x)
+    sd_bf = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 and "embedding" not in k else v) for k, v in sd.items()}
+    want = CO.clip_vision_forward(sd_bf, x, heads, patch)["image_embeds"]
+    assert got.shape == (2, 64)
+    assert rel(got, want) < 2e-2, rel(got, want)
+    assert rel(got, torch.from_numpy(z["image_embeds"])) < 3e-2

@@ -47,3 +47,21 @@ def test_softmax_rows_and_f32_gemm():
     p = torch.empty(2, 192, 256, device="cuda", dtype=torch.bfloat16)
     L.check(lib.tmix_softmax_rows(s.data_ptr(), 256, p.data_ptr(), 256, 2 * 192, 256, 0.0884, torch.cuda.current_stream().cuda_stream))
     torch.testing.assert_close(p.float(), torch.softmax(ref * 0.0884, -1), rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_vae_encoder_matches_oracle(size):
+    """VAEEncoderPlan (conv_in on 3 fp32 planes, asymmetric stride-2 convs, single-head mid attention) against the fp32 restatement."""
+    from tweediemix_amd import vae as V
+    from oracle import vae_oracle as VO
+    cfg, H, W = (V.TINY, 64, 128) if size == "tiny" else (V.FULL, 128, 256)      # (H/8)*(W/8) % 64 == 0 for the PV GEMM
+    sd = V.synthetic_state_dict(cfg, seed=7, nontrivial=True, encoder=True)
+    if size == "full":
+        assert sum(v.numel() for k, v in sd.items() if k.startswith("encoder.")) == 34_163_592
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(2, 3, H, W, generator=g) * 2 - 1
+    mean, logvar = V.VAEEncoderPlan(cfg, sd, 2, H, W)(img.cuda())
+    want_m, want_l = VO.VAEDecoderOracle(cfg, sd).encode(img)
+    assert mean.shape == want_m.shape == (2, 4, H // 8, W // 8)
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(mean, want_m) < 2e-2 and rel(logvar, want_l) < 2e-2, (rel(mean, want_m), rel(logvar, want_l))

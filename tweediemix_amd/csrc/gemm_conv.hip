@@ -174,6 +174,7 @@ gemm_conv_kernel(const Params p) {
             int iy, ix; bool ok;
             if (p.mode == TMIX_CONV_S1 || p.mode == TMIX_CONV_T3) { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
             else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else if (p.mode == TMIX_CONV_S2A) { iy = 2 * py[r] + ky; ix = 2 * px[r] + kx; ok = (iy < p.H) & (ix < p.Wd); }   // pad right / bottom only
             else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
                    ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
             const unsigned sw = LW ? swp[r & 1] : (unsigned)asw[LW ? 0 : r];
@@ -683,15 +684,16 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: empty problem");
     if (d->Cin % BK) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: Cin=%d must be a multiple of %d", d->Cin, BK);
     if (d->Cout % 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: Cout=%d must be a multiple of 4", d->Cout);
-    if (d->mode < TMIX_CONV_S1 || d->mode > TMIX_CONV_T3) TMIX_FAIL(TMIX_EINVAL, "conv3x3: bad mode %d", d->mode);
-    if (d->mode == TMIX_CONV_S2 && ((d->H | d->W) & 1)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: stride-2 needs even H,W");
+    if (d->mode < TMIX_CONV_S1 || d->mode > TMIX_CONV_S2A) TMIX_FAIL(TMIX_EINVAL, "conv3x3: bad mode %d", d->mode);
+    if ((d->mode == TMIX_CONV_S2 || d->mode == TMIX_CONV_S2A) && ((d->H | d->W) & 1)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: stride-2 needs even H,W");
     if (!aligned16(d->X) || !aligned16(d->Wt) || (((uintptr_t)d->Y) & 7)) TMIX_FAIL(TMIX_EALIGN, "conv3x3: pointer alignment");
     if ((d->bias && (((uintptr_t)d->bias) & 15)) || (d->batch_bias && (((uintptr_t)d->batch_bias) & 15))) TMIX_FAIL(TMIX_EALIGN, "conv3x3: bias alignment");
     Params p = {};
     p.H = d->H; p.Wd = d->W; p.Cin = d->Cin; p.mode = d->mode;
     p.ntaps = d->mode == TMIX_CONV_T3 ? 3 : 9;
-    p.Ho = d->mode == TMIX_CONV_S2 ? d->H / 2 : (d->mode == TMIX_CONV_UP2 ? d->H * 2 : d->H);
-    p.Wo = d->mode == TMIX_CONV_S2 ? d->W / 2 : (d->mode == TMIX_CONV_UP2 ? d->W * 2 : d->W);
+    const bool half = d->mode == TMIX_CONV_S2 || d->mode == TMIX_CONV_S2A;
+    p.Ho = half ? d->H / 2 : (d->mode == TMIX_CONV_UP2 ? d->H * 2 : d->H);
+    p.Wo = half ? d->W / 2 : (d->mode == TMIX_CONV_UP2 ? d->W * 2 : d->W);
     const int64_t M = (int64_t)d->B * p.Ho * p.Wo;
     if (M > 0x7fffffff / 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: too many output pixels");
     if ((int64_t)d->B * d->H * d->W * d->Cin >= (1ll << 30) || (int64_t)d->Cout * 9 * d->Cin >= (1ll << 30)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: operand larger than 2 GiB");

@@ -187,12 +187,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const bf16_t* __restrict
 // one workgroup per row; the row (<= 64K columns) is streamed three times from L2/HBM (max, sum, write).
 // seq > 0: causal rows of a [.., seq, cols] score stack -- row r attends to columns <= r % seq, the rest get P = 0.
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ S, int64_t ld_s, bf16_t* __restrict__ P,
-                                                           int64_t ld_p, int cols, float scale_log2e, int seq) {
+                                                           int64_t ld_p, int cols, float scale_log2e, int seq, int valid) {
     __shared__ float red[4];
     const float* row = S + (int64_t)blockIdx.x * ld_s;
     bf16_t* out = P + (int64_t)blockIdx.x * ld_p;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lim = seq > 0 ? (int)(blockIdx.x % (unsigned)seq) + 1 : cols;     // visible columns: [0, lim)
+    const int lim = seq > 0 ? (int)(blockIdx.x % (unsigned)seq) + 1 : valid;    // visible columns: [0, lim)
     auto load = [&](int c) {
         float4 v = *(const float4*)(row + c);
         if (c + 0 >= lim) v.x = -INFINITY;
@@ -554,7 +554,7 @@ extern "C" int tmix_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t 
     if (!S || !P) TMIX_FAIL(TMIX_EINVAL, "softmax_rows: null pointer");
     if (rows <= 0 || cols <= 0 || (cols % 4) || (ld_s % 4) || (ld_p % 4)) TMIX_FAIL(TMIX_ESHAPE, "softmax_rows: rows=%lld cols=%d (cols, ld %% 4 == 0)", (long long)rows, cols);
     if (!aligned16(S) || (((uintptr_t)P) & 7)) TMIX_FAIL(TMIX_EALIGN, "softmax_rows: pointer alignment");
-    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, 0);
+    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, 0, cols);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
@@ -565,7 +565,18 @@ extern "C" int tmix_softmax_rows_causal(const float* S, int64_t ld_s, void* P, i
     if (rows <= 0 || cols <= 0 || seq <= 0 || seq > cols || (rows % seq) || (cols % 4) || (ld_s % 4) || (ld_p % 4))
         TMIX_FAIL(TMIX_ESHAPE, "softmax_rows_causal: rows=%lld cols=%d seq=%d (rows %% seq == 0, seq <= cols, cols/ld %% 4 == 0)", (long long)rows, cols, seq);
     if (!aligned16(S) || (((uintptr_t)P) & 7)) TMIX_FAIL(TMIX_EALIGN, "softmax_rows_causal: pointer alignment");
-    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, seq);
+    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, seq, cols);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_softmax_rows_masked(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int cols, int valid, float scale,
+                                        void* stream) {
+    if (!S || !P) TMIX_FAIL(TMIX_EINVAL, "softmax_rows_masked: null pointer");
+    if (rows <= 0 || cols <= 0 || valid < 1 || valid > cols || (cols % 4) || (ld_s % 4) || (ld_p % 4))
+        TMIX_FAIL(TMIX_ESHAPE, "softmax_rows_masked: rows=%lld cols=%d valid=%d", (long long)rows, cols, valid);
+    if (!aligned16(S) || (((uintptr_t)P) & 7)) TMIX_FAIL(TMIX_EALIGN, "softmax_rows_masked: pointer alignment");
+    softmax_rows_kernel<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S, ld_s, (bf16_t*)P, ld_p, cols, scale * 1.4426950408889634f, 0, valid);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
@@ -611,19 +622,22 @@ extern "C" int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const 
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv_in: bad shape");
     if (!aligned16(y_nhwc)) TMIX_FAIL(TMIX_EALIGN, "conv_in: output must be 16-byte aligned");
     if (Cout % 32) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d must be a multiple of 32", Cout);
-    if (Cin != 4 && Cin != 8) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (4: image latent, 8: video latent + image-latent features)", Cin);
-    if (Cin == 8 && pre_w) TMIX_FAIL(TMIX_EINVAL, "conv_in: the latent pre-map is defined for 4 channels");
+    if (Cin != 3 && Cin != 4 && Cin != 8) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cin=%d (3: RGB image, 4: image latent, 8: video latent + image-latent features)", Cin);
+    if (Cin != 4 && pre_w) TMIX_FAIL(TMIX_EINVAL, "conv_in: the latent pre-map is defined for 4 channels");
+    if ((Cout * 9 * Cin) % 4) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout*9*Cin must be a multiple of 4");
     if (!aligned16(w_ohwi)) TMIX_FAIL(TMIX_EALIGN, "conv_in: weights must be 16-byte aligned");
     const int64_t npix = (int64_t)B * H * W;
     const unsigned nb = (unsigned)((npix + 63) / 64);
     const int smem = Cout * 9 * Cin * 4;
     if (smem > 150 * 1024) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d too large for the LDS weight stage", Cout);
-    static int attr_smem[2] = {0, 0};
-    if (smem > 64 * 1024 && smem > attr_smem[Cin == 8]) {
+    static int attr_smem[3] = {0, 0, 0};
+    const int slot = Cin == 8 ? 2 : (Cin == 4 ? 1 : 0);
+    if (smem > 64 * 1024 && smem > attr_smem[slot]) {
         hipError_t e = Cin == 8 ? hipFuncSetAttribute((const void*)conv_in_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)
-                                : hipFuncSetAttribute((const void*)conv_in_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                     : Cin == 4 ? hipFuncSetAttribute((const void*)conv_in_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)
+                                : hipFuncSetAttribute((const void*)conv_in_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_smem[Cin == 8] = smem;
+        attr_smem[slot] = smem;
     }
     PreMap pm = {};
     if (pre_w) {
@@ -633,6 +647,7 @@ extern "C" int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const 
     }
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 8) conv_in_kernel<8><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
+    else if (Cin == 3) conv_in_kernel<3><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
     else          conv_in_kernel<4><<<nb, 256, smem, st>>>(x_nchw, w_ohwi, bias, (bf16_t*)y_nhwc, B, H, W, Cout, pm);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;

@@ -14,7 +14,7 @@ OK, EINVAL, ESHAPE, EARCH, EALIGN = 0, -1, -2, -3, -4
 F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
-CONV_S1, CONV_S2, CONV_UP2, CONV_T3 = 0, 1, 2, 3
+CONV_S1, CONV_S2, CONV_UP2, CONV_T3, CONV_S2A = 0, 1, 2, 3, 4
 TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 11, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -57,6 +57,7 @@ SIGNATURES = {
     "tmix_conv_in_pre": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "tmix_softmax_rows": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, f32, vp]),
     "tmix_softmax_rows_causal": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, f32, C.c_int, vp]),
+    "tmix_softmax_rows_masked": (C.c_int, [vp, i64, vp, i64, i64, C.c_int, C.c_int, f32, vp]),
     "tmix_affine_clamp": (C.c_int, [vp, vp, i64, f32, f32, f32, f32, vp]),
     "tmix_conv_out": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tmix_attn_fwd": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,

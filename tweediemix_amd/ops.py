@@ -158,7 +158,7 @@ def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.
 
 
 def conv_out_hw(H, W, mode):
-    return (H // 2, W // 2) if mode == L.CONV_S2 else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
+    return (H // 2, W // 2) if mode in (L.CONV_S2, L.CONV_S2A) else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
 
 
 def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0):
@@ -329,3 +329,13 @@ def temporal_attention(qkv, clips, frames, heads, scale=None, out=None):
     L.check(L.load().tmix_temporal_attn(_p(qkv), qkv.stride(1), _p(out), out.stride(1), clips, frames, hw, heads,
                                         float(scale if scale is not None else 64 ** -0.5), _stream()), "tmix_temporal_attn")
     return out
+
+
+def softmax_rows_masked(scores, probs, valid, scale):
+    """probs[r, c] = softmax over the first `valid` columns of scale * scores[r] (bf16), zeros in the padding columns."""
+    _need_cuda(scores, probs)
+    rows, cols = scores.shape
+    assert scores.dtype == torch.float32 and probs.dtype == BF16 and probs.shape == scores.shape
+    L.check(L.load().tmix_softmax_rows_masked(_p(scores), scores.stride(0), _p(probs), probs.stride(0), rows, cols, int(valid),
+                                              float(scale), _stream()), "tmix_softmax_rows_masked")
+    return probs

@@ -359,3 +359,104 @@ class TextPath:
         null = [opt.negative_prompt]
         return (get_text_embeds(self.encoders, self.tokenizers, prompts, null),
                 get_text_embeds(self.encoders, self.tokenizers, prompts_single, null), K)
+
+
+# ============================================================================================ vision tower
+class ClipVisionEncoder:
+    """CLIP image tower (transformers CLIPVisionModelWithProjection; OpenCLIP ViT-H/14 in the I2VGen-XL pipeline's `_encode_image`:
+    32 layers, d=1280, 16 heads of 80) on the HIP kernels.  The patch convolution is a GEMM over unfolded patches (K padded to a
+    multiple of 64); heads of 80 are zero-padded to 128 columns in the fused q/k projection so the score GEMM has a legal K;
+    scores / probabilities live in rows padded to a multiple of 64 keys (`tmix_softmax_rows_masked` zeroes the padding)."""
+
+    HP = 128                         # padded head size of q / k
+
+    def __init__(self, sd: dict, heads: int, patch: int, act: str = "gelu", eps: float = 1e-5, device="cuda"):
+        sd = {(k[len("vision_model."):] if k.startswith("vision_model.") else k): v for k, v in sd.items()}
+        self.dev, self.heads, self.patch, self.act, self.eps = torch.device(device), heads, patch, act, eps
+        dev = self.dev
+        f32 = lambda k: sd[k].to(dev, F32).contiguous()
+        bf = lambda t: t.to(dev, BF16).contiguous()
+        wp = sd["embeddings.patch_embedding.weight"].to(dev, F32)                    # [d, 3, p, p]
+        self.d = d = wp.shape[0]
+        self.hd = d // heads
+        assert self.hd <= self.HP and self.hd % 4 == 0
+        k0 = wp[0].numel()
+        self.kp = (k0 + 63) // 64 * 64
+        wpad = torch.zeros(d, self.kp, device=dev, dtype=F32)
+        wpad[:, :k0] = wp.reshape(d, k0)
+        self.patch_w = bf(wpad)
+        self.cls, self.pos = f32("embeddings.class_embedding"), f32("embeddings.position_embedding.weight")
+        self.pre_ln = (f32("pre_layrnorm.weight"), f32("pre_layrnorm.bias"))
+        self.post_ln = (f32("post_layernorm.weight"), f32("post_layernorm.bias"))
+        self.proj = bf(sd["visual_projection.weight"])
+        self.n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
+        HP, hd = self.HP, self.hd
+
+        def pad_heads(w, b):         # [d, d] / [d] -> [heads*HP, d] / [heads*HP], rows h*HP .. h*HP+hd-1 carry head h
+            wo = torch.zeros(heads * HP, d, device=dev, dtype=F32)
+            bo = torch.zeros(heads * HP, device=dev, dtype=F32)
+            for h in range(heads):
+                wo[h * HP:h * HP + hd] = w[h * hd:(h + 1) * hd]
+                bo[h * HP:h * HP + hd] = b[h * hd:(h + 1) * hd]
+            return wo, bo
+
+        self.layers = []
+        for i in range(self.n_layers):
+            p = f"encoder.layers.{i}."
+            a = p + "self_attn."
+            wq, bq = pad_heads(sd[a + "q_proj.weight"].to(dev, F32), sd[a + "q_proj.bias"].to(dev, F32))
+            wk, bk = pad_heads(sd[a + "k_proj.weight"].to(dev, F32), sd[a + "k_proj.bias"].to(dev, F32))
+            self.layers.append(dict(
+                ln1=(f32(p + "layer_norm1.weight"), f32(p + "layer_norm1.bias")),
+                qkv=bf(torch.cat([wq, wk, sd[a + "v_proj.weight"].to(dev, F32)])),
+                qkv_b=torch.cat([bq, bk, sd[a + "v_proj.bias"].to(dev, F32)]).contiguous(),
+                out=bf(sd[a + "out_proj.weight"]), out_b=f32(a + "out_proj.bias"),
+                ln2=(f32(p + "layer_norm2.weight"), f32(p + "layer_norm2.bias")),
+                fc1=bf(sd[p + "mlp.fc1.weight"]), fc1_b=f32(p + "mlp.fc1.bias"),
+                fc2=bf(sd[p + "mlp.fc2.weight"]), fc2_b=f32(p + "mlp.fc2.bias")))
+
+    def _layer(self, x, lw, B, S):
+        d, H, HP, hd = self.d, self.heads, self.HP, self.hd
+        M = B * S
+        KP = (S + 63) // 64 * 64                                      # padded key axis (K of the PV product)
+        NK = (S + 3) // 4 * 4
+        QK = 2 * H * HP
+        y = ops.layernorm(x, lw["ln1"][0], lw["ln1"][1], self.eps)
+        qk = torch.zeros(M + 8, QK, device=self.dev, dtype=BF16)
+        vt = torch.zeros(B, d, KP, device=self.dev, dtype=BF16)
+        ops.gemm(y.view(B, S, d), lw["qkv"], out=qk[:M].view(B, S, QK), bias=lw["qkv_b"], out_t=vt, n_trans_begin=QK)
+        ao = torch.empty(M, d, device=self.dev, dtype=BF16)
+        scores = torch.empty(H, S, KP, device=self.dev, dtype=F32)
+        probs = torch.empty(H, S, KP, device=self.dev, dtype=BF16)
+        for b in range(B):
+            q = qk[b * S:b * S + S].as_strided((H, S, HP), (HP, QK, 1))
+            k = qk[b * S:].as_strided((H, NK, HP), (HP, QK, 1), storage_offset=qk[b * S:].storage_offset() + H * HP)
+            ops.gemm(q, k, out_f32=scores[:, :, :NK])
+            ops.softmax_rows_masked(scores.view(H * S, KP), probs.view(H * S, KP), S, hd ** -0.5)
+            o = ao[b * S:b * S + S].as_strided((H, S, hd), (hd, d, 1))
+            ops.gemm(probs, vt[b].view(H, hd, KP), out=o)
+        x = ops.gemm(ao, lw["out"], bias=lw["out_b"], residual=x)
+        y = ops.layernorm(x, lw["ln2"][0], lw["ln2"][1], self.eps)
+        h = ops.gemm(y, lw["fc1"], bias=lw["fc1_b"], act=self.act)
+        return ops.gemm(h, lw["fc2"], bias=lw["fc2_b"], residual=x)
+
+    @torch.no_grad()
+    def __call__(self, pixel_values: torch.Tensor):
+        """pixel_values [B,3,H,W] (already normalised) -> image_embeds [B, projection_dim] fp32."""
+        pv = pixel_values.to(self.dev, F32)
+        B, _c, Hh, Ww = pv.shape
+        p = self.patch
+        gh, gw = Hh // p, Ww // p
+        S = gh * gw + 1
+        assert S == self.pos.shape[0], "position table is for a different image size"
+        patches = pv.unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5).reshape(B * gh * gw, -1)      # [B*N, 3*p*p]
+        a = torch.zeros(B * gh * gw, self.kp, device=self.dev, dtype=BF16)
+        a[:, :patches.shape[1]] = patches.to(BF16)
+        emb = ops.gemm(a, self.patch_w).view(B, gh * gw, self.d).float()
+        x = torch.cat([self.cls.expand(B, 1, self.d), emb], dim=1) + self.pos[None]
+        x = ops.layernorm(x.to(BF16).reshape(B * S, self.d).contiguous(), self.pre_ln[0], self.pre_ln[1], self.eps)
+        for lw in self.layers:
+            x = self._layer(x, lw, B, S)
+        cls = x.view(B, S, self.d)[:, 0].contiguous()
+        pooled = ops.layernorm(cls, self.post_ln[0], self.post_ln[1], self.eps).float().contiguous()
+        return ops.linear_small(pooled, self.proj)

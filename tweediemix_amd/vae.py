@@ -62,10 +62,49 @@ def param_shapes(cfg) -> dict:
     return P
 
 
-def synthetic_state_dict(cfg, seed=4321, device="cpu", nontrivial=False):
+def encoder_param_shapes(cfg) -> dict:
+    """AutoencoderKL encoder + quant_conv (diffusers Encoder / DownEncoderBlock2D; FULL: 34,163,592 + 72 parameters)."""
+    P = {}
+    ch = list(cfg["block_out_channels"])
+    lc = cfg["latent_channels"]
+
+    def conv(n, i, o, k=3):
+        P[n + ".weight"] = (o, i, k, k)
+        P[n + ".bias"] = (o,)
+
+    def vec2(n, c):
+        P[n + ".weight"] = (c,)
+        P[n + ".bias"] = (c,)
+
+    def resnet(n, ci, co):
+        vec2(n + ".norm1", ci); conv(n + ".conv1", ci, co); vec2(n + ".norm2", co); conv(n + ".conv2", co, co)
+        if ci != co:
+            conv(n + ".conv_shortcut", ci, co, 1)
+
+    conv("encoder.conv_in", cfg["out_channels"], ch[0])
+    ci = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(cfg["layers_per_block"]):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", ci, co)
+            ci = co
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co)
+    resnet("encoder.mid_block.resnets.0", ci, ci)
+    vec2("encoder.mid_block.attentions.0.group_norm", ci)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        P[f"encoder.mid_block.attentions.0.{nm}.weight"] = (ci, ci)
+        P[f"encoder.mid_block.attentions.0.{nm}.bias"] = (ci,)
+    resnet("encoder.mid_block.resnets.1", ci, ci)
+    vec2("encoder.conv_norm_out", ci)
+    conv("encoder.conv_out", ci, 2 * lc)
+    conv("quant_conv", 2 * lc, 2 * lc, 1)
+    return P
+
+
+def synthetic_state_dict(cfg, seed=4321, device="cpu", nontrivial=False, encoder=False):
     gen = torch.Generator(device=device).manual_seed(seed)
     sd = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in (encoder_param_shapes(cfg) if encoder else param_shapes(cfg)).items():
         is_norm = "norm" in name
         if name.endswith(".bias"):
             v = torch.randn(shape, generator=gen, device=device) * 0.05 if nontrivial else torch.zeros(shape, device=device)
@@ -78,7 +117,7 @@ def synthetic_state_dict(cfg, seed=4321, device="cpu", nontrivial=False):
             v = torch.randn(shape, generator=gen, device=device) * fan ** -0.5
             if ".conv2." in name or ".to_out.0." in name:
                 v = v * 0.3
-        sd[name] = v.to(BF16).float() if not name.startswith(("post_quant_conv", "decoder.conv_in")) else v.float()
+        sd[name] = v.to(BF16).float() if not name.startswith(("post_quant_conv", "decoder.conv_in", "quant_conv", "encoder.conv_in")) else v.float()
     return sd
 
 
@@ -231,3 +270,78 @@ class VAEDecoderPlan:
         self.latent.copy_(latent)
         self.run()
         return self.image
+
+
+class VAEEncoderPlan(VAEDecoderPlan):
+    """encode(image [B,3,H,W] fp32 in [-1,1]) -> (mean, logvar) [B,4,H/8,W/8] fp32 of AutoencoderKL.encode (the I2VGen-XL pipeline's
+    `prepare_image_latents`, video_gen/pipeline_i2vgen_xl.py:421-451, samples from it and scales by 0.18215).  Same emitters as the
+    decoder; the stride-2 convs pad right / bottom only (`TMIX_CONV_S2A`), conv_in takes the 3 RGB planes in fp32."""
+
+    def __init__(self, cfg, sd, B, H, W, device="cuda"):
+        self.cfg, self.B, self.H, self.Wd = cfg, B, H, W
+        self.dev = torch.device(device)
+        self.lib = L.load()
+        self.ops, self.keep = [], []
+        self.arena = _Arena(self.dev)
+        self.flops = 0
+        dev = self.dev
+        t = {}
+        for k, v in sd.items():
+            if not k.startswith(("encoder.", "quant_conv")):
+                continue
+            v = v.to(dev)
+            if k.endswith(".bias") or "norm" in k:
+                t[k] = v.to(F32).contiguous()
+            elif v.dim() == 4 and v.shape[-1] == 3 and not k.startswith("encoder.conv_in"):
+                t[k] = v.permute(0, 2, 3, 1).to(BF16).contiguous()
+            elif v.dim() == 4 and v.shape[-1] == 1 and not k.startswith("quant_conv"):
+                t[k] = v.reshape(v.shape[0], v.shape[1]).to(BF16).contiguous()
+            elif v.dim() == 2:
+                t[k] = v.to(BF16).contiguous()
+        t["encoder.conv_in.weight"] = sd["encoder.conv_in.weight"].to(dev, F32).permute(0, 2, 3, 1).contiguous()
+        a = "encoder.mid_block.attentions.0"
+        t[a + ".qkv"] = torch.cat([t[a + ".to_q.weight"], t[a + ".to_k.weight"], t[a + ".to_v.weight"]]).contiguous()
+        t[a + ".qkv.bias"] = torch.cat([t[a + ".to_q.bias"], t[a + ".to_k.bias"], t[a + ".to_v.bias"]]).contiguous()
+        self.t = t
+        lc = cfg["latent_channels"]
+        self.qw = sd["quant_conv.weight"].to(dev, F32).reshape(2 * lc, 2 * lc)
+        self.qb = sd["quant_conv.bias"].to(dev, F32)
+        self.image = torch.zeros(B, cfg["out_channels"], H, W, device=dev, dtype=F32)
+        nl = len(cfg["block_out_channels"]) - 1
+        self.moments = torch.zeros(B, 2 * lc, H >> nl, W >> nl, device=dev, dtype=F32)
+        self._gn_ws = ops.groupnorm_ws(B, 4096, cfg["groups"], dev)
+        self._build()
+
+    def _build(self):
+        cfg, A, B, lib, t = self.cfg, self.arena, self.B, self.lib, self.t
+        ch = list(cfg["block_out_channels"])
+        Hh, Ww = self.H, self.Wd
+        x = A.get(B, Hh * Ww, ch[0])
+        self._emit(lib.tmix_conv_in, self.image.data_ptr(), t["encoder.conv_in.weight"].data_ptr(), t["encoder.conv_in.bias"].data_ptr(),
+                   x.data_ptr(), B, cfg["out_channels"], Hh, Ww, ch[0])
+        ci = ch[0]
+        for i, co in enumerate(ch):
+            for j in range(cfg["layers_per_block"]):
+                x2 = self._resnet(x, ci, co, Hh, Ww, f"encoder.down_blocks.{i}.resnets.{j}")
+                A.put(x)
+                x, ci = x2, co
+            if i < len(ch) - 1:
+                x2 = self._conv(x, f"encoder.down_blocks.{i}.downsamplers.0.conv", Hh, Ww, co, co, mode=L.CONV_S2A)
+                A.put(x)
+                x = x2
+                Hh, Ww = Hh // 2, Ww // 2
+        x2 = self._resnet(x, ci, ci, Hh, Ww, "encoder.mid_block.resnets.0"); A.put(x)
+        x3 = self._attn(x2, ci, Hh, Ww, "encoder.mid_block.attentions.0"); A.put(x2)
+        x = self._resnet(x3, ci, ci, Hh, Ww, "encoder.mid_block.resnets.1"); A.put(x3)
+        y = self._gn(x, ci, Hh * Ww, "encoder.conv_norm_out", True)
+        A.put(x)
+        self._emit(lib.tmix_conv_out, y.data_ptr(), t["encoder.conv_out.weight"].data_ptr(), t["encoder.conv_out.bias"].data_ptr(),
+                   self.moments.data_ptr(), B, ci, Hh, Ww, 2 * cfg["latent_channels"])
+
+    def __call__(self, image):
+        """-> (mean, logvar) after quant_conv (an 8x8 per-pixel map on the 1/8-resolution moments: a torch einsum on a 64x64 grid)."""
+        self.image.copy_(image)
+        self.run()
+        m = torch.einsum("oc,bchw->bohw", self.qw, self.moments) + self.qb[None, :, None, None]
+        lc = self.cfg["latent_channels"]
+        return m[:, :lc].contiguous(), m[:, lc:].clamp(-30.0, 20.0).contiguous()
