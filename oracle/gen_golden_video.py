@@ -50,3 +50,30 @@ for dt_name, dt in (("f32", torch.float32), ("f16", torch.float16)):
         out[k + ".meta"] = np.array([1 if sched else 0, 1 if sched2 else 0, interp or 0.0, t, int(t in (sched or sched2)) or int(t == 1000)], np.float64)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "video_step.npz"), **out)
 print("wrote", len(out), "arrays")
+
+# ---- image side of the pipeline: _center_crop_wide / _resize_bilinear (:759-793) and prepare_image_latents (:421-451)
+import PIL.Image
+src = "\n".join(pl)
+fn_src = src[src.index("def _resize_bilinear("):]
+fn_src = fn_src[:fn_src.index("def _convert_pt_to_pil")] if "def _convert_pt_to_pil" in fn_src else fn_src
+env = {"torch": torch, "PIL": PIL, "Union": __import__("typing").Union, "List": __import__("typing").List, "Tuple": __import__("typing").Tuple,
+       "_convert_pt_to_pil": lambda im: im}
+exec(fn_src, env)
+rs = np.random.RandomState(5)
+img = PIL.Image.fromarray(rs.randint(0, 256, (90, 150, 3), dtype=np.uint8))
+out2 = {"img": np.array(img)}
+for tag, res in (("sq", (64, 64)), ("wide", (96, 56))):
+    out2[f"crop.{tag}"] = np.array(env["_center_crop_wide"](img, res))
+out2["resize.224"] = np.array(env["_resize_bilinear"](env["_center_crop_wide"](img, (64, 64)), (32, 32)))
+pil = textwrap.dedent("\n".join(pl[427:450]))          # body of prepare_image_latents after `image = image.to(device)`
+class _Dist:
+    def __init__(self, m): self.m = m
+    def sample(self): return self.m
+mean = torch.randn(1, 4, 7, 12, generator=g)
+self = types.SimpleNamespace(vae=types.SimpleNamespace(encode=lambda im: types.SimpleNamespace(latent_dist=_Dist(mean)), config=types.SimpleNamespace(scaling_factor=0.18215)),
+                             do_classifier_free_guidance=True)
+env3 = {"self": self, "torch": torch, "image": torch.zeros(1), "device": "cpu", "num_frames": 16, "num_videos_per_prompt": 1}
+exec(pil, env3)
+out2["pil.mean"] = mean.numpy(); out2["pil.out"] = env3["image_latents"].numpy()
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "video_image.npz"), **out2)
+print("wrote video_image.npz", {k: v.shape for k, v in out2.items()})

@@ -4,12 +4,11 @@
 The reference script hard-codes its inputs and pulls `ali-vilab/i2vgen-xl` from the hub; here the same settings are flags
 with the reference's values as defaults, and the model comes from local files:
 
-  --i2v_path           diffusers-layout I2VGen-XL folder: unet/diffusion_pytorch_model[.fp16].safetensors (+ vae/ for frames)
-  --conditioning_path  torch file with what the pipeline computes before its loop (video_gen/pipeline_i2vgen_xl.py:604-639):
-                       {'image_embeddings': [2,1024] (zeros row first), 'image_latents': [2,4,F,h,w], optionally
-                        'prompt_embeds': [2,77,1024] (negative row first)}.  Without prompt_embeds the text half runs natively
-                       from <i2v_path>/tokenizer + text_encoder (tweediemix_amd/text.py); the ViT-H VISION tower (head size 80)
-                       and the VAE ENCODER behind the two image tensors are not rebuilt in this repository yet
+  --i2v_path           diffusers-layout I2VGen-XL folder: unet/, tokenizer/ + text_encoder/, image_encoder/ (+ feature_extractor/),
+                       vae/ -- prompt embeddings, the CLIP image embedding and the image latents are computed natively from
+                       --prompt / --negative_prompt / --image_path (tweediemix_amd/text.py, vae.py, video.py)
+  --conditioning_path  optional torch file with any of {'prompt_embeds': [2,77,1024] (negative row first), 'image_embeddings':
+                       [2,1024] (zeros row first), 'image_latents': [2,4,F,h,w]} to use instead of computing them
   --alphas_cumprod     .npy with the checkpoint scheduler's 1000-entry table (else: cosine schedule with zero terminal SNR)
   --synthetic          random-init network and conditioning of the real shapes (no checkpoints exist offline)
 
@@ -55,6 +54,46 @@ def build_parser():
     return p
 
 
+def native_conditioning(opt, gen, have):
+    """what I2VGenXLPipeline.__call__ computes before its loop (video_gen/pipeline_i2vgen_xl.py:604-639), from the checkpoint's
+    tokenizer/ + text_encoder/ (prompt embeddings), image_encoder/ (CLIP image embedding) and vae/ (image latents); entries
+    already present in the --conditioning_path file are kept."""
+    import json
+    from PIL import Image
+    from fusion_generation.fusion_sampling import find_weights, load_state_dict
+    from tweediemix_amd import text as T, vae as VA, video as V
+    out = {}
+    root = opt.i2v_path
+    if "prompt_embeds" not in have:                     # encode_prompt: negative row first (CFG order)
+        tok = T.ClipBPETokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+        enc = T.load_text_tower(os.path.join(root, "text_encoder"))
+        out["prompt_embeds"] = enc.last_hidden_state(tok([opt.negative_prompt, opt.prompt])).float().cpu()
+    if "image_embeddings" in have and "image_latents" in have:
+        return out
+    image = Image.open(opt.image_path).convert("RGB")
+    if "image_embeddings" not in have:                  # :623-628 + _encode_image: crop to (w, w), bilinear to the tower's size, CLIP stats
+        icfg = json.load(open(os.path.join(root, "image_encoder", "config.json")))
+        fx = os.path.join(root, "feature_extractor", "preprocessor_config.json")
+        fcfg = json.load(open(fx)) if os.path.exists(fx) else {}
+        size = icfg.get("image_size", 224)
+        tower = T.ClipVisionEncoder(load_state_dict(find_weights(os.path.join(root, "image_encoder"), "model")), icfg["num_attention_heads"],
+                                    icfg["patch_size"], icfg.get("hidden_act", "gelu"), icfg.get("layer_norm_eps", 1e-5))
+        crop = V.resize_bilinear(V.center_crop_wide(image, (opt.width, opt.width)), (size, size))
+        kw = {k: tuple(fcfg[k2]) for k, k2 in (("mean", "image_mean"), ("std", "image_std")) if k2 in fcfg}
+        emb = tower(V.clip_pixel_values(crop, **kw)).float().cpu()
+        out["image_embeddings"] = torch.cat([torch.zeros_like(emb), emb])
+    if "image_latents" not in have:                     # :631-639 prepare_image_latents
+        vdir = os.path.join(root, "vae")
+        j = json.load(open(os.path.join(vdir, "config.json")))
+        vcfg = dict(block_out_channels=tuple(j["block_out_channels"]), layers_per_block=j.get("layers_per_block", 2),
+                    latent_channels=j.get("latent_channels", 4), out_channels=j.get("out_channels", 3), groups=j.get("norm_num_groups", 32))
+        encp = VA.VAEEncoderPlan(vcfg, load_state_dict(find_weights(vdir, "diffusion_pytorch_model")), 1, opt.height, opt.width)
+        mean, logvar = encp(V.vae_pixel_values(V.center_crop_wide(image, (opt.width, opt.height))).cuda())
+        sample = mean.cpu() + torch.exp(0.5 * logvar.cpu()) * torch.randn(mean.shape, generator=gen)       # latent_dist.sample()
+        out["image_latents"] = V.prepare_image_latents(sample, opt.num_frames, j.get("scaling_factor", 0.18215))
+    return out
+
+
 def main(argv=None):
     opt = build_parser().parse_args(argv)
     from tweediemix_amd import i2vgen as I, ops, video as V
@@ -69,16 +108,12 @@ def main(argv=None):
         cond = {"prompt_embeds": torch.randn(2, 77, cfg.cross_dim, generator=gen), "image_embeddings": torch.randn(2, cfg.cross_dim, generator=gen),
                 "image_latents": torch.randn(2, 4, Fr, h, w, generator=gen)}
     else:
-        if not (opt.i2v_path and opt.conditioning_path):
-            sys.exit("need --i2v_path and --conditioning_path (or --synthetic); there is no hub download here")
+        if not opt.i2v_path:
+            sys.exit("need --i2v_path (or --synthetic); there is no hub download here")
         from fusion_generation.fusion_sampling import find_weights, load_state_dict
         sd = load_state_dict(find_weights(os.path.join(opt.i2v_path, "unet"), "diffusion_pytorch_model"))
-        cond = torch.load(opt.conditioning_path, map_location="cpu")
-        if "prompt_embeds" not in cond:      # text half natively: tokenizer/ + text_encoder/ of the checkpoint (encode_prompt, CFG order)
-            from tweediemix_amd import text as T
-            tok = T.ClipBPETokenizer.from_pretrained(os.path.join(opt.i2v_path, "tokenizer"))
-            enc = T.load_text_tower(os.path.join(opt.i2v_path, "text_encoder"))
-            cond["prompt_embeds"] = enc.last_hidden_state(tok([opt.negative_prompt, opt.prompt])).float().cpu()
+        cond = torch.load(opt.conditioning_path, map_location="cpu") if opt.conditioning_path else {}
+        cond.update(native_conditioning(opt, gen, cond))
     Wt = I.I2VWeights(cfg, sd)
     fps = torch.tensor([float(opt.target_fps)] * 2)
     fe, ctx, ilf = I.conditioning(Wt, fps, cond["image_latents"], cond["image_embeddings"], cond["prompt_embeds"])

@@ -134,3 +134,22 @@ def test_prompt_assembly_and_token_injection_match_reference_vectors(golden_dir)
         torch.testing.assert_close(encs[0].tok[50:], torch.tensor(c["table_rows"]))
         torch.testing.assert_close(encs[1].tok[60:], torch.tensor(c["table_rows_2"]))
     assert T.inject_modifier_tokens(toks, encs, [{"unet": {}}], ["<x>"]) == ([], [])        # no 'modifier_token' in sts[0]: untouched
+
+
+def test_video_image_preprocessing_matches_reference_vectors(golden_dir):
+    """video.center_crop_wide / resize_bilinear / prepare_image_latents against outputs of the reference's own functions
+    (tests/golden/video_image.npz, oracle/gen_golden_video.py)."""
+    import os
+    import numpy as np
+    import torch
+    from PIL import Image
+    from tweediemix_amd import video as V
+    z = np.load(os.path.join(golden_dir, "video_image.npz"))
+    img = Image.fromarray(z["img"])
+    assert np.array_equal(np.array(V.center_crop_wide(img, (64, 64))), z["crop.sq"])
+    assert np.array_equal(np.array(V.center_crop_wide(img, (96, 56))), z["crop.wide"])
+    assert np.array_equal(np.array(V.resize_bilinear(V.center_crop_wide(img, (64, 64)), (32, 32))), z["resize.224"])
+    got = V.prepare_image_latents(torch.from_numpy(z["pil.mean"]), 16)
+    assert np.array_equal(got.numpy(), z["pil.out"])
+    pv = V.clip_pixel_values(img)
+    assert pv.shape == (1, 3, 90, 150) and abs(float(pv.mean())) < 3

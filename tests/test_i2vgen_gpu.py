@@ -128,3 +128,49 @@ def test_run_video_drop_in(tmp_path, monkeypatch):
     lat2 = rv.main(["--synthetic", "--tiny", "--height", "128", "--width", "64", "--num_inference_steps", "10", "--seed", "3",
                     "--injection_timestep", "0.2", "--no_graphs"])
     assert torch.equal(lat.cpu(), lat2.cpu())                        # graph replay == eager
+
+
+def test_run_video_from_image_and_prompt(tmp_path, monkeypatch, golden_dir):
+    """run_video.py with nothing precomputed, on a synthetic diffusers-layout I2VGen-XL folder: tokenizer + text tower, CLIP image
+    tower + preprocessing, VAE encoder + frame-position planes, UNet loop, VAE decode to a GIF."""
+    import importlib.util, json, os, shutil
+    import numpy as np
+    from PIL import Image
+    from safetensors.torch import save_file
+    from tweediemix_amd import i2vgen as I, vae as V, weights as Wt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = tmp_path / "i2v"
+    cfg = I.TINY                                           # cross_dim 128
+    (ck / "unet").mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in Wt.synthetic_i2vgen_state_dict(cfg).items()}, str(ck / "unet" / "diffusion_pytorch_model.safetensors"))
+    z = np.load(os.path.join(golden_dir, "clip_text.npz"))       # text tower: the tiny CLIP of the golden set (d = 128)
+    sd = {k[len("l") + 4:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("l.sd.")}
+    key = [k for k in sd if k.endswith("token_embedding.weight")][0]
+    g = torch.Generator().manual_seed(1)
+    sd[key] = torch.cat([sd[key], torch.randn(620 - 64, 128, generator=g) * 0.05])
+    (ck / "text_encoder").mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(ck / "text_encoder" / "model.safetensors"))
+    json.dump({"hidden_act": "quick_gelu", "num_attention_heads": 2, "eos_token_id": 2}, open(ck / "text_encoder" / "config.json", "w"))
+    shutil.copytree(os.path.join(golden_dir, "clip_tok"), ck / "tokenizer")
+    zv = np.load(os.path.join(golden_dir, "clip_vision.npz"))    # image tower: the golden tiny ViT (56x56, patch 14, proj 64 -> need 128)
+    vsd = {k[3:]: torch.from_numpy(zv[k].astype(np.float32)) for k in zv.files if k.startswith("sd.")}
+    vsd["visual_projection.weight"] = torch.randn(128, 320, generator=g) * 320 ** -0.5
+    (ck / "image_encoder").mkdir()
+    save_file({k: v.contiguous() for k, v in vsd.items()}, str(ck / "image_encoder" / "model.safetensors"))
+    json.dump({"image_size": 56, "patch_size": 14, "num_attention_heads": 4, "hidden_act": "gelu"}, open(ck / "image_encoder" / "config.json", "w"))
+    (ck / "vae").mkdir()
+    vae_sd = V.synthetic_state_dict(V.TINY, nontrivial=True)
+    vae_sd.update(V.synthetic_state_dict(V.TINY, seed=9, nontrivial=True, encoder=True))
+    save_file({k: v.contiguous() for k, v in vae_sd.items()}, str(ck / "vae" / "diffusion_pytorch_model.safetensors"))
+    json.dump({"block_out_channels": list(V.TINY["block_out_channels"]), "layers_per_block": 1}, open(ck / "vae" / "config.json", "w"))
+    img = tmp_path / "init.png"
+    Image.fromarray(np.random.RandomState(0).randint(0, 256, (200, 300, 3), dtype=np.uint8)).save(img)
+    spec = importlib.util.spec_from_file_location("run_video_cli2", os.path.join(root, "run_video.py"))
+    rv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rv)
+    monkeypatch.chdir(tmp_path)
+    lat = rv.main(["--i2v_path", str(ck), "--vae_path", str(ck / "vae"), "--image_path", str(img), "--tiny", "--height", "64", "--width", "128",
+                   "--num_inference_steps", "4", "--seed", "5", "--prompt", "a cat and a dog running", "--negative_prompt", "blurry"])
+    assert lat.shape == (1, 4, 16, 8, 16) and torch.isfinite(lat).all()
+    gif = Image.open(tmp_path / "output_i2v_seed_5.gif")
+    assert gif.n_frames == 16 and gif.size == (128, 64)

@@ -72,3 +72,41 @@ def sample_loop(unet, latents: torch.Tensor, schedule: VideoSchedule, guidance_s
         v = unet(torch.cat([x, x]), int(t)).contiguous()
         x = ops.vpred_step(x, v, guidance_scale, schedule.alpha(int(t)), schedule.alpha(int(t) - schedule.skip))
     return x
+
+
+# ------------------------------------------------------------------------------------------ image side of the pipeline (host)
+def center_crop_wide(image, resolution):
+    """video_gen/pipeline_i2vgen_xl.py:772-793: BOX-resize so the image covers `resolution` (w, h), then centre crop (PIL)."""
+    import PIL.Image
+    scale = min(image.size[0] / resolution[0], image.size[1] / resolution[1])
+    image = image.resize((round(image.width // scale), round(image.height // scale)), resample=PIL.Image.BOX)
+    x1 = (image.width - resolution[0]) // 2
+    y1 = (image.height - resolution[1]) // 2
+    return image.crop((x1, y1, x1 + resolution[0], y1 + resolution[1]))
+
+
+def resize_bilinear(image, resolution):
+    """:759-769."""
+    import PIL.Image
+    return image.resize(resolution, PIL.Image.BILINEAR)
+
+
+def clip_pixel_values(image, mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711)):
+    """`_encode_image` (:300-315): PIL -> [0,1] float -> CLIP normalisation, no further resize / crop.  [1,3,H,W] fp32."""
+    a = torch.from_numpy(np.asarray(image, np.float32) / 255.0).permute(2, 0, 1)[None]
+    return (a - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
+
+
+def vae_pixel_values(image):
+    """VideoProcessor.preprocess: PIL -> [-1,1] float, [1,3,H,W]."""
+    return torch.from_numpy(np.asarray(image, np.float32) / 255.0).permute(2, 0, 1)[None] * 2.0 - 1.0
+
+
+def prepare_image_latents(latent_sample, num_frames, scaling_factor=0.18215, cfg=True):
+    """:421-451 after `vae.encode(image).latent_dist.sample()`: scale, add the frame axis, append one constant plane per later
+    frame holding its position (frame_idx+1)/(num_frames-1) in all 4 channels, duplicate for classifier-free guidance."""
+    il = (latent_sample * scaling_factor).unsqueeze(2)
+    masks = [torch.ones_like(il[:, :, :1]) * ((f + 1) / (num_frames - 1)) for f in range(num_frames - 1)]
+    if masks:
+        il = torch.cat([il, torch.cat(masks, dim=2)], dim=2)
+    return torch.cat([il] * 2) if cfg else il
