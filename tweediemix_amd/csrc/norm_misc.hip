@@ -322,8 +322,11 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < Cout * KK / 4; i += 256) ((float4*)s_w)[i] = ((const float4*)w)[i];
+    __syncthreads();
     const int64_t npix = (int64_t)B * H * W;
-    int64_t pix = (int64_t)blockIdx.x * 64 + lane;
+    // persistent over 64-pixel tiles: the weight stage (up to 92 KB) is paid once per workgroup, not once per 64 pixels
+    for (int64_t tile = blockIdx.x; tile * 64 < npix; tile += gridDim.x) {
+    int64_t pix = tile * 64 + lane;
     const bool live = pix < npix;
     if (!live) pix = npix - 1;
     const int b = (int)(pix / ((int64_t)H * W)); const int rem = (int)(pix - (int64_t)b * H * W);
@@ -349,11 +352,11 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) patch[(ky * 3 + kx) * CIN + ci] = v[ci];
         }
-    __syncthreads();
     const int cpq = Cout / 4;                      // output channels per wave (multiple of 8)
     for (int c0 = q * cpq; c0 < (q + 1) * cpq; c0 += 8) {
         float o[8];
-#pragma unroll
+        // (CIN = 8: 72-tap patches; unrolling all 8 filters at once spills 160 registers to scratch and runs 6x slower per flop)
+#pragma unroll 2
         for (int j = 0; j < 8; ++j) {
             const float* wr = s_w + (c0 + j) * KK;
             float a = bias ? bias[c0 + j] : 0.f;
@@ -362,6 +365,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
             o[j] = a;
         }
         if (live) *(uint4*)(y + pix * Cout + c0) = pack8(o);
+    }
     }
 }
 
@@ -627,8 +631,10 @@ extern "C" int tmix_conv_in_pre(const float* x_nchw, const float* w_ohwi, const 
     if ((Cout * 9 * Cin) % 4) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout*9*Cin must be a multiple of 4");
     if (!aligned16(w_ohwi)) TMIX_FAIL(TMIX_EALIGN, "conv_in: weights must be 16-byte aligned");
     const int64_t npix = (int64_t)B * H * W;
-    const unsigned nb = (unsigned)((npix + 63) / 64);
+    const int64_t ntiles = (npix + 63) / 64;
     const int smem = Cout * 9 * Cin * 4;
+    const int per_cu = smem > 80 * 1024 ? 1 : (smem > 52 * 1024 ? 2 : 3);            // resident workgroups per CU (LDS)
+    const unsigned nb = (unsigned)(ntiles < 256 * per_cu ? ntiles : 256 * per_cu);
     if (smem > 150 * 1024) TMIX_FAIL(TMIX_ESHAPE, "conv_in: Cout=%d too large for the LDS weight stage", Cout);
     static int attr_smem[3] = {0, 0, 0};
     const int slot = Cin == 8 ? 2 : (Cin == 4 ? 1 : 0);
