@@ -23,5 +23,16 @@ for kind in ("custom", "lora"):
         print(kind, streams, seeds, "->", len(U._TUNE_CACHE), "shapes", flush=True)
         del tw
         torch.cuda.empty_cache()
+# the video UNet (BASELINE config #5): CFG pair of 16-frame clips at 768x448 and 512x512
+from tweediemix_amd import i2vgen as I
+from tweediemix_amd.weights import synthetic_i2vgen_state_dict
+Wv = I.I2VWeights(I.FULL, {k: v.to(torch.bfloat16) for k, v in synthetic_i2vgen_state_dict(I.FULL).items()})
+g = torch.Generator().manual_seed(0)
+for hh, ww in ((56, 96), (64, 64)):
+    il = torch.randn(2, 4, 16, hh, ww, generator=g)
+    fe, ctx, ilf = I.conditioning(Wv, torch.tensor([8.0, 8.0]), il, torch.randn(2, 1024, generator=g), torch.randn(2, 77, 1024, generator=g))
+    I.I2VPlan(Wv, 2, 16, hh, ww, fe, ctx, ilf)
+    print("video", hh, ww, "->", len(U._TUNE_CACHE), "shapes", flush=True)
+    torch.cuda.empty_cache()
 U.save_tune_table(out)
 print("wrote", out, len(U._TUNE_CACHE))
