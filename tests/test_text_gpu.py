@@ -107,3 +107,15 @@ def test_vision_tower_matches_oracle_and_transformers_vectors(golden_dir):
     assert got.shape == (2, 64)
     assert rel(got, want) < 2e-2, rel(got, want)
     assert rel(got, torch.from_numpy(z["image_embeds"])) < 3e-2
+
+
+def test_full_size_vision_tower_matches_oracle():
+    """OpenCLIP ViT-H/14 image tower at its real size (32 x 1280, 16 heads of 80, 257 tokens, projection 1024), random-init weights."""
+    from tweediemix_amd import text as T, weights as Wt
+    from oracle import clip_oracle as CO
+    sd = Wt.synthetic_clip_vision_state_dict(1280, 32, 5120, 16, dtype=torch.bfloat16)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(4))
+    got = T.ClipVisionEncoder(sd, 16, 14)(x)
+    want = CO.clip_vision_forward({k: v.float() for k, v in sd.items()}, x, 16, 14)["image_embeds"]
+    assert got.shape == (1, 1024)
+    assert rel(got, want) < 3e-2, rel(got, want)

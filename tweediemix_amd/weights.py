@@ -300,3 +300,26 @@ def synthetic_i2vgen_state_dict(cfg, seed=99, dtype=torch.float32):
     return sd
 
 
+
+
+def synthetic_clip_vision_state_dict(d: int, layers: int, inter: int, heads: int, patch: int = 14, image: int = 224, proj: int = 1024,
+                                     seed: int = 78, dtype=torch.float32):
+    """random-init CLIP image tower in transformers' CLIPVisionModelWithProjection key scheme."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std=1.0: (torch.randn(*s, generator=g) * std).to(dtype)
+    n = (image // patch) ** 2 + 1
+    sd = {"vision_model.embeddings.class_embedding": rn(d, std=0.02),
+          "vision_model.embeddings.patch_embedding.weight": rn(d, 3, patch, patch, std=(3 * patch * patch) ** -0.5),
+          "vision_model.embeddings.position_embedding.weight": rn(n, d, std=0.02)}
+    for nm in ("pre_layrnorm", "post_layernorm"):
+        sd[f"vision_model.{nm}.weight"], sd[f"vision_model.{nm}.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    for i in range(layers):
+        p = f"vision_model.encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{nm}.weight"], sd[p + f"self_attn.{nm}.bias"] = rn(d, d, std=d ** -0.5), rn(d, std=0.02)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = rn(inter, d, std=d ** -0.5), rn(inter, std=0.02)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = rn(d, inter, std=inter ** -0.5), rn(d, std=0.02)
+        for nm in ("layer_norm1", "layer_norm2"):
+            sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    sd["visual_projection.weight"] = rn(proj, d, std=d ** -0.5)
+    return sd
