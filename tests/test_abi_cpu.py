@@ -51,3 +51,28 @@ def test_ops_refuse_cpu_tensors():
     from tweediemix_amd import lib, ops
     with pytest.raises(lib.TmixError):
         ops.gemm(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+
+
+def test_argument_errors_are_reported_before_any_launch():
+    """every entry point validates its arguments first and returns a TMIX_E* code with a message (no GPU needed to see that)."""
+    import ctypes as C
+    from tweediemix_amd import lib
+    l = lib.load()
+    fake = C.c_void_p(0x1000)                   # aligned, never dereferenced: validation fails first
+    cases = [
+        (l.tmix_vpred_step(None, None, None, 0, 16, 1.0, 1.0, 0.0, 1.0, 0.0, None), "vpred_step"),
+        (l.tmix_vpred_step(fake, fake, fake, 7, 16, 1.0, 1.0, 0.0, 1.0, 0.0, None), "dtype"),
+        (l.tmix_frame_inject(fake, 0, 2, 1, 64, 1, 0.0, 0.0, None), "frames"),
+        (l.tmix_temporal_attn(fake, 3 * 64, fake, 64, 1, 17, 4, 1, 0.125, None), "frames"),
+        (l.tmix_temporal_attn(fake, 64, fake, 64, 1, 16, 4, 1, 0.125, None), "ld"),
+        (l.tmix_softmax_rows_causal(fake, 128, fake, 128, 10, 128, 1.0, 3, None), "seq"),
+        (l.tmix_softmax_rows_masked(fake, 128, fake, 128, 10, 128, 0, 1.0, None), "valid"),
+        (l.tmix_conv_in(fake, fake, None, fake, 1, 5, 8, 8, 64, None), "Cin"),
+    ]
+    for rc, word in cases:
+        assert rc < 0, word
+    assert l.tmix_gemm_stats_parts(1280, 7) == 8 and l.tmix_gemm_stats_parts(1280, 1) == 10 and l.tmix_gemm_stats_parts(1280, 99) == -1
+    bm, bn = C.c_int(), C.c_int()
+    assert l.tmix_gemm_tile_shape(9, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (256, 128)
+    d = lib.GemmDesc()
+    assert l.tmix_gemm_bf16(C.byref(d), None) < 0 and b"null" in l.tmix_last_error_string()
