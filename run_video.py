@@ -51,6 +51,7 @@ def build_parser():
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--tiny", action="store_true", help="tiny network (smoke tests)")
     p.add_argument("--no_graphs", action="store_true")
+    p.add_argument("--streams", type=int, default=2, choices=[1, 2], help="2: the two clips of the CFG pair run as two launch chains")
     return p
 
 
@@ -117,7 +118,7 @@ def main(argv=None):
     Wt = I.I2VWeights(cfg, sd)
     fps = torch.tensor([float(opt.target_fps)] * 2)
     fe, ctx, ilf = I.conditioning(Wt, fps, cond["image_latents"], cond["image_embeddings"], cond["prompt_embeds"])
-    plan = I.I2VPlan(Wt, 2, Fr, h, w, fe, ctx, ilf, interp=opt.interp_ratio)
+    plan = (I.I2VPlanGroup if opt.streams == 2 else I.I2VPlan)(Wt, 2, Fr, h, w, fe, ctx, ilf, interp=opt.interp_ratio)
     if opt.alphas_cumprod:
         acp = np.load(opt.alphas_cumprod).astype(np.float32)
     else:                                   # stand-in table: squaredcos_cap_v2 betas rescaled to zero terminal SNR
@@ -132,9 +133,12 @@ def main(argv=None):
     graphs = {}
 
     def unet(xin, t):                                               # one recorded forward per injection state, replayed as a hipGraph
-        xv = plan.x_in.view(2, Fr, 2 * cfg.in_channels, h, w)
-        xv[:, :, :cfg.in_channels] = xin.permute(0, 2, 1, 3, 4)
-        plan.t_dev.fill_(float(t))
+        if opt.streams == 2:
+            plan.set_input(xin, t)
+        else:
+            xv = plan.x_in.view(2, Fr, 2 * cfg.in_channels, h, w)
+            xv[:, :, :cfg.in_channels] = xin.permute(0, 2, 1, 3, 4)
+            plan.t_dev.fill_(float(t))
         if opt.no_graphs:
             plan.run()
         else:

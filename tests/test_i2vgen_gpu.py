@@ -174,3 +174,22 @@ def test_run_video_from_image_and_prompt(tmp_path, monkeypatch, golden_dir):
     assert lat.shape == (1, 4, 16, 8, 16) and torch.isfinite(lat).all()
     gif = Image.open(tmp_path / "output_i2v_seed_5.gif")
     assert gif.n_frames == 16 and gif.size == (128, 64)
+
+
+def test_plan_group_equals_single_plan():
+    """the CFG pair split over two streams gives the single plan's result bit for bit (with and without injection)."""
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I
+    B, Fr, H, W = 2, 16, 16, 8
+    sd, il, emb, ehs, fps, sample = _setup(IO.TINY, I.TINY, B, Fr, H, W, 13)
+    Wt = I.I2VWeights(I.TINY, sd)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    one = I.I2VPlan(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    grp = I.I2VPlanGroup(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    for inj in (False, True):
+        one.inject = inj
+        grp.inject = inj
+        a = one(sample, 701).clone()
+        b = grp(sample, 701).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), float((a - b).abs().max())

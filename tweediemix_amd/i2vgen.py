@@ -418,3 +418,54 @@ class I2VPlan(UNetPlan):
         self.t_dev.fill_(float(t))
         self.run()
         return self.eps.view(self.clips, self.frames, cfg.out_channels, self.h, self.w).permute(0, 2, 1, 3, 4)
+
+
+class I2VPlanGroup:
+    """the clips of one UNet call (the unconditional and the text row of the CFG pair) as independent launch chains on their own
+    HIP streams -- the same trick as the image sampler's PlanGroup: a dependent chain leaves the chip idle at every kernel
+    boundary, the other clip's chain fills the holes (measured 103 -> 97 ms per step at 16 x 768 x 448).  Interface of I2VPlan."""
+
+    def __init__(self, W: I2VWeights, clips: int, frames: int, h: int, w: int, fps_emb, context, il_feat, autotune: bool = True,
+                 interp: float = 0.7):
+        self.cfg, self.clips, self.frames, self.h, self.w = W.cfg, clips, frames, h, w
+        self.plans = [I2VPlan(W, 1, frames, h, w, fps_emb[i:i + 1], context[i:i + 1], il_feat[i:i + 1], autotune=autotune, interp=interp)
+                      for i in range(clips)]
+        self.streams = [None] + [torch.cuda.Stream(device=W.device) for _ in range(clips - 1)]
+        self.eps = torch.zeros(clips * frames, W.cfg.out_channels, h, w, device=W.device, dtype=F32)
+        self.flops = sum(p.flops for p in self.plans)
+        self.ops = [op for p in self.plans for op in p.ops]
+
+    inject = property(lambda self: self.plans[0].inject, lambda self, v: [setattr(p, "inject", v) for p in self.plans])
+    interp = property(lambda self: self.plans[0].interp, lambda self, v: [setattr(p, "interp", v) for p in self.plans])
+
+    def set_input(self, sample, t):
+        """sample [clips,4,F,h,w] (or [1,...] broadcast to every clip)."""
+        c = self.cfg.in_channels
+        for i, p in enumerate(self.plans):
+            s = sample[i if sample.shape[0] > 1 else 0]
+            p.x_in.view(self.frames, 2 * c, self.h, self.w)[:, :c] = s.to(p.dev, F32).permute(1, 0, 2, 3)
+            p.t_dev.fill_(float(t))
+
+    def run(self):
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for p, st in zip(self.plans[1:], self.streams[1:]):
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                p.run()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                joins.append(ev)
+        self.plans[0].run()
+        for ev in joins:
+            main.wait_event(ev)
+        n = self.frames
+        for i, p in enumerate(self.plans):
+            self.eps[i * n:(i + 1) * n].copy_(p.eps)
+
+    def __call__(self, sample, t):
+        self.set_input(sample, t)
+        self.run()
+        return self.eps.view(self.clips, self.frames, self.cfg.out_channels, self.h, self.w).permute(0, 2, 1, 3, 4)
