@@ -1,0 +1,29 @@
+"""cold-operand single launches (the in-sequence regime): tmix_gemm_bf16 next to torch.matmul (hipBLASLt) after a cache flush,
+with A warm (just written by the previous kernel in the real sequence) and W cold."""
+import os, sys, ctypes as C, torch
+sys.path.insert(0, os.getcwd())
+from tweediemix_amd import ops, lib as L
+lib = L.load(); BF = torch.bfloat16
+st = torch.cuda.current_stream().cuda_stream
+junk = torch.empty(1 << 29, device="cuda", dtype=torch.int16)
+def once(fn, warm):
+    ts = []
+    for _ in range(7):
+        junk.add_(1)
+        for t in warm: t.float().sum()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[1]
+for (M, N, K) in ((4096, 1280, 1280), (4096, 3840, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (16384, 640, 640), (16384, 5120, 640)):
+    a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+    out = torch.empty(M, N, device="cuda", dtype=BF)
+    wt = w.t()
+    best = None
+    for cfg in (1, 2, 7, 9):
+        d = ops.make_gemm_desc(a, w, out, tile_cfg=cfg)
+        t = once(lambda: lib.tmix_gemm_bf16(C.byref(d), st), [a])
+        best = min(best, (t, cfg)) if best else (t, cfg)
+    tb = once(lambda: torch.matmul(a, wt, out=out), [a])
+    print(f"{M}x{N}x{K}: A warm / W cold: tmix cfg{best[1]} {best[0]:6.1f} us | torch.matmul {tb:6.1f} us", flush=True)
