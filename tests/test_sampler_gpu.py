@@ -334,3 +334,23 @@ def test_cli_sd_path_prompts_to_png(tmp_path, golden_dir):
     want_e, want_p = CO.encode_prompt(enc, ids)
     rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
     assert rel(te[0], want_e) < 2e-2 and rel(te[1], want_p) < 3e-2
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (tiny network, 2 steps)."""
+    need_gpu()
+    import json, subprocess, sys
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, _os.path.join(root, "bench.py"), "--tiny", "--res", "256", "--steps", "2", "--warmup", "1",
+                        "--cpu-threads", "8"], capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
