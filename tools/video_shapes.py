@@ -25,7 +25,7 @@ for i, fn, e0, e1 in evs:
     if i in tun:
         k, d = tun[i]
         key = ("gemm", d.batch, d.M, d.N, d.K, d.epilogue, d.tile_cfg) if k == "gemm" else ("conv", d.B, d.H, d.W, d.Cin, d.Cout, d.mode, d.tile_cfg)
-        fl = 2 * d.batch * d.M * d.N * d.K if k == "gemm" else 2 * d.B * d.H * d.W * d.Cout * (3 if d.mode == 3 else 9) * d.Cin / (4 if d.mode in (1, 4) else 1)
+        fl = 2 * d.batch * d.M * d.N * d.K if k == "gemm" else 2 * d.B * d.H * d.W * d.Cout * (3 if d.mode == 3 else 9) * d.Cin * (0.25 if d.mode in (1, 4) else 4 if d.mode == 2 else 1)
     else:
         key, fl = (getattr(fn, "__name__", "op"),), 0
     agg[key][0] += 1; agg[key][1] += ms; agg[key][2] += fl
