@@ -85,7 +85,8 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_256x256_S2 = 4, TMIX_TILE_256x128_W4 = 5, TMIX_TILE_256x256_W4 = 6, TMIX_TILE_128x160_S2 = 7,
        /* the same tilings with one extra LOADER wave that issues every LDS-DMA (the math waves only read LDS and issue MFMAs) */
        TMIX_TILE_128x160_S2_LW = 8, TMIX_TILE_256x128_S3_LW = 9, TMIX_TILE_128x128_S2_LW = 10, TMIX_TILE_256x256_S2_LW = 11,
-       TMIX_TILE_COUNT = 11 };
+       TMIX_TILE_128x160_S4 = 12 /* tiling 7 with a 4-deep LDS ring (one workgroup per CU) */,
+       TMIX_TILE_COUNT = 12 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

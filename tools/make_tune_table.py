@@ -18,7 +18,9 @@ for kind in ("custom", "lora"):
         args = argparse.Namespace(kind=kind, res=1024, tiny=False, no_graphs=True, streams=streams, seeds_per_gpu=seeds)
         tw, _ = bench.build_sampler(args, dev, seed=7)
         for name in ("fusion", "fusion_base", "plain", "start"):          # every phase's plan (B = K+1, K+1, 2, K+1 rows)
-            tw.plan(name)
+            pl = tw.plan(name)
+            if name == "fusion" and hasattr(pl, "refine") and seeds == 1:   # the headline configuration: re-rank under two-chain load
+                print("refined group step:", pl.refine(verbose=True), "ms", flush=True)
         tw.plans.clear()
         print(kind, streams, seeds, "->", len(U._TUNE_CACHE), "shapes", flush=True)
         del tw

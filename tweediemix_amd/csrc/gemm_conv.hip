@@ -554,7 +554,9 @@ struct TileCfg { int bm, bn; };
 // for this path's M = 4096 / 16384 GEMMs, i.e. whole rounds on 256 CUs instead of 1.25 / 2.5.
 // 8..11 = tilings 7, 2, 1, 4 with one extra LOADER wave (wave specialisation, see gemm_conv_kernel); the 4-wave tilings
 // with 128-wide wave tiles (5, 6) have no registers for a fifth wave on one of the SIMDs
-constexpr int NUM_CFG = 11;
+// 12 = tiling 7 (128x160) with a 4-deep ring (one workgroup per CU, three K-tiles in flight: the in-sequence loop is bound by
+// memory latency x bytes in flight, and 160-wide tiles divide N = 1280 / 640 exactly)
+constexpr int NUM_CFG = 12;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -586,7 +588,7 @@ template <int CONV>
 int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
     if (p.n_trans_begin >= 0) {                                                // transposed stores need square wave tiles
-        if (cfg == 4 || cfg == 5 || cfg == 7) cfg = 2;
+        if (cfg == 4 || cfg == 5 || cfg == 7 || cfg == 12) cfg = 2;
         if (cfg == 6 && (p.n_trans_begin % 256)) cfg = 2;                     // the boundary must fall on a tile edge (N = 3 x 320: 640)
         if (cfg == 8 || cfg == 11) cfg = 9;
     }
@@ -598,6 +600,7 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
     case 5: return launch_cfg<256, 128, 2, 2, 3, CONV>(p, batch, st);
     case 6: return launch_cfg<256, 256, 2, 2, 2, CONV>(p, batch, st);
     case 7: return launch_cfg<128, 160, 4, 1, 2, CONV>(p, batch, st);
+    case 12: return launch_cfg<128, 160, 4, 1, 4, CONV>(p, batch, st);
     default: break;
     }
     // loader-wave variants exist for the plain GEMM only: the im2col gather's per-row offset tables do not fit the loader's
@@ -624,7 +627,7 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
 
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
-                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}};
+                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

@@ -363,11 +363,11 @@ class UNetPlan:
             # the loader-wave tilings (8..11) win isolated launches by 7-27 % and in-sequence eager launches by 2-4 %, but a
             # 9-wave / 147 KB workgroup owns its CU: in graph replay the next kernel (or the other chain) cannot move in
             # while it drains, and whole steps came out 0-3 % SLOWER -- so they are candidates only on request
-            ncand_gemm = L.TILE_COUNT if os.environ.get("TMIX_TUNE_LW") else L.TILE_COUNT_CONV
+            cands = list(L.TILE_CANDIDATES) + (list(L.TILE_LW) if os.environ.get("TMIX_TUNE_LW") else [])
             for _rep in range(reps):
-                for cfg in range(1, ncand_gemm + 1):
+                for cfg in cands:
                     for _i, kind, d in tun:
-                        d.tile_cfg = cfg if (kind == "gemm" or cfg <= L.TILE_COUNT_CONV) else 1
+                        d.tile_cfg = cfg if (kind == "gemm" or cfg not in L.TILE_LW) else 1
                     self._link_ln()
                     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in tun]
                     for i, (fn, args) in enumerate(self.ops):
@@ -387,8 +387,8 @@ class UNetPlan:
                         best_t[(k, cfg)] = min(best_t.get((k, cfg), float("inf")), t)
             for k in set(keys):
                 if k not in _TUNE_CACHE:
-                    ncand = ncand_gemm if k.startswith("('gemm'") else L.TILE_COUNT_CONV
-                    _TUNE_CACHE[k] = min(range(1, ncand + 1), key=lambda c: best_t[(k, c)])
+                    ok = [c for c in cands if k.startswith("('gemm'") or c not in L.TILE_LW]
+                    _TUNE_CACHE[k] = min(ok, key=lambda c: best_t[(k, c)])
         for (_i, _kind, d), k in zip(tun, keys):
             d.tile_cfg = _TUNE_CACHE[k]
         self._link_ln()
@@ -678,6 +678,60 @@ class PlanGroup:
         self.gemm_flops = sum(p.gemm_flops for p in self.plans)
         self.launches = {k: [x for p in self.plans for x in p.launches[k]] for k in ("gemm", "conv", "attn")}
         self.ops = [op for p in self.plans for op in p.ops]
+
+    def refine(self, top=14, reps=9, verbose=False):
+        """second tuning pass for the chains of a group: UNetPlan.autotune ranks tilings with one chain running alone, but a
+        tiling that owns its CU (one workgroup, deep ring) can lose once the other chain competes for the same CUs.  For the
+        `top` heaviest launch shapes every candidate is tried in place and the WHOLE group is timed as a captured graph
+        (median of `reps` replays); the winner replaces the cache entry.  Used offline by tools/make_tune_table.py."""
+        def timed():
+            self.run()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run()
+            for _ in range(2):
+                g.replay()
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
+
+        weight, members = {}, {}
+        for p in self.plans:
+            for _i, kind, d in p._tunable:
+                k = p._tune_key(kind, d)
+                fl = 2.0 * d.M * d.N * d.K * d.batch if kind == "gemm" else 2.0 * d.B * d.H * d.W * d.Cout * 9 * d.Cin
+                weight[k] = weight.get(k, 0.0) + fl
+                members.setdefault(k, []).append((p, kind, d))
+        base = timed()
+        for k in sorted(weight, key=weight.get, reverse=True)[:top]:
+            cur = members[k][0][2].tile_cfg
+            best, best_t = cur, base
+            for cfg in L.TILE_CANDIDATES:
+                if cfg == cur:
+                    continue
+                for p, _kind, d in members[k]:
+                    d.tile_cfg = cfg
+                for p in self.plans:
+                    p._link_ln()
+                t = timed()
+                if t < best_t - 0.02:                       # 20 us: above the replay-to-replay noise of the median
+                    best, best_t = cfg, t
+            for p, _kind, d in members[k]:
+                d.tile_cfg = best
+            for p in self.plans:
+                p._link_ln()
+            if verbose:
+                print(f"  refine {k}: {cur} -> {best}  ({base:.3f} -> {best_t:.3f} ms)", flush=True)
+            _TUNE_CACHE[k] = best
+            base = best_t
+        return base
 
     def run(self):
         main = torch.cuda.current_stream()
