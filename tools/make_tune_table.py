@@ -34,6 +34,9 @@ for hh, ww in ((56, 96), (64, 64)):
     il = torch.randn(2, 4, 16, hh, ww, generator=g)
     fe, ctx, ilf = I.conditioning(Wv, torch.tensor([8.0, 8.0]), il, torch.randn(2, 1024, generator=g), torch.randn(2, 77, 1024, generator=g))
     I.I2VPlan(Wv, 2, 16, hh, ww, fe, ctx, ilf)
+    grp = I.I2VPlanGroup(Wv, 2, 16, hh, ww, fe, ctx, ilf)              # run_video's default: one chain per clip
+    print("refined video step:", grp.refine(verbose=True, reps=5), "ms", flush=True)
+    del grp
     print("video", hh, ww, "->", len(U._TUNE_CACHE), "shapes", flush=True)
     torch.cuda.empty_cache()
 U.save_tune_table(out)

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from . import ops
-from .unet import UNetPlan, _Arena, BF16, F32
+from .unet import UNetPlan, _Arena, BF16, F32, refine_group
 from .weights import fold_layernorm, interleave_geglu
 
 
@@ -437,6 +437,9 @@ class I2VPlanGroup:
 
     inject = property(lambda self: self.plans[0].inject, lambda self, v: [setattr(p, "inject", v) for p in self.plans])
     interp = property(lambda self: self.plans[0].interp, lambda self, v: [setattr(p, "interp", v) for p in self.plans])
+
+    def refine(self, **kw):
+        return refine_group(self, **kw)
 
     def set_input(self, sample, t):
         """sample [clips,4,F,h,w] (or [1,...] broadcast to every clip)."""

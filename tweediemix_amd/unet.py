@@ -648,6 +648,62 @@ class UNetPlan:
         return self.eps
 
 
+def refine_group(self, top=14, reps=9, verbose=False):
+    """second tuning pass for the chains of a group: UNetPlan.autotune ranks tilings with one chain running alone, but a
+    tiling that owns its CU (one workgroup, deep ring) can lose once the other chain competes for the same CUs.  For the
+    `top` heaviest launch shapes every candidate is tried in place and the WHOLE group is timed as a captured graph
+    (median of `reps` replays); the winner replaces the cache entry.  Used offline by tools/make_tune_table.py."""
+    def timed():
+        self.run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run()
+        for _ in range(2):
+            g.replay()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    weight, members = {}, {}
+    for p in self.plans:
+        for _i, kind, d in p._tunable:
+            k = p._tune_key(kind, d)
+            fl = 2.0 * d.M * d.N * d.K * d.batch if kind == "gemm" else 2.0 * d.B * d.H * d.W * d.Cout * 9 * d.Cin
+            weight[k] = weight.get(k, 0.0) + fl
+            members.setdefault(k, []).append((p, kind, d))
+    base = timed()
+    for k in sorted(weight, key=weight.get, reverse=True)[:top]:
+        cur = members[k][0][2].tile_cfg
+        best, best_t = cur, base
+        for cfg in L.TILE_CANDIDATES:
+            if cfg == cur:
+                continue
+            for p, _kind, d in members[k]:
+                d.tile_cfg = cfg
+            for p in self.plans:
+                p._link_ln()
+            t = timed()
+            if t < best_t - 0.02:                       # 20 us: above the replay-to-replay noise of the median
+                best, best_t = cfg, t
+        for p, _kind, d in members[k]:
+            d.tile_cfg = best
+        for p in self.plans:
+            p._link_ln()
+        if verbose:
+            print(f"  refine {k}: {cur} -> {best}  ({base:.3f} -> {best_t:.3f} ms)", flush=True)
+        _TUNE_CACHE[k] = best
+        base = best_t
+    return base
+
+
+
 class PlanGroup:
     """The batch rows of one UNet call split into `n_groups` independent sub-plans, each enqueued on its own HIP
     stream (rows never interact inside the UNet).  Dependent launches of one chain leave the chip partly idle at
@@ -679,59 +735,8 @@ class PlanGroup:
         self.launches = {k: [x for p in self.plans for x in p.launches[k]] for k in ("gemm", "conv", "attn")}
         self.ops = [op for p in self.plans for op in p.ops]
 
-    def refine(self, top=14, reps=9, verbose=False):
-        """second tuning pass for the chains of a group: UNetPlan.autotune ranks tilings with one chain running alone, but a
-        tiling that owns its CU (one workgroup, deep ring) can lose once the other chain competes for the same CUs.  For the
-        `top` heaviest launch shapes every candidate is tried in place and the WHOLE group is timed as a captured graph
-        (median of `reps` replays); the winner replaces the cache entry.  Used offline by tools/make_tune_table.py."""
-        def timed():
-            self.run()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.run()
-            for _ in range(2):
-                g.replay()
-            ts = []
-            for _ in range(reps):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                g.replay()
-                e1.record()
-                e1.synchronize()
-                ts.append(e0.elapsed_time(e1))
-            return sorted(ts)[len(ts) // 2]
-
-        weight, members = {}, {}
-        for p in self.plans:
-            for _i, kind, d in p._tunable:
-                k = p._tune_key(kind, d)
-                fl = 2.0 * d.M * d.N * d.K * d.batch if kind == "gemm" else 2.0 * d.B * d.H * d.W * d.Cout * 9 * d.Cin
-                weight[k] = weight.get(k, 0.0) + fl
-                members.setdefault(k, []).append((p, kind, d))
-        base = timed()
-        for k in sorted(weight, key=weight.get, reverse=True)[:top]:
-            cur = members[k][0][2].tile_cfg
-            best, best_t = cur, base
-            for cfg in L.TILE_CANDIDATES:
-                if cfg == cur:
-                    continue
-                for p, _kind, d in members[k]:
-                    d.tile_cfg = cfg
-                for p in self.plans:
-                    p._link_ln()
-                t = timed()
-                if t < best_t - 0.02:                       # 20 us: above the replay-to-replay noise of the median
-                    best, best_t = cfg, t
-            for p, _kind, d in members[k]:
-                d.tile_cfg = best
-            for p in self.plans:
-                p._link_ln()
-            if verbose:
-                print(f"  refine {k}: {cur} -> {best}  ({base:.3f} -> {best_t:.3f} ms)", flush=True)
-            _TUNE_CACHE[k] = best
-            base = best_t
-        return base
+    def refine(self, **kw):
+        return refine_group(self, **kw)
 
     def run(self):
         main = torch.cuda.current_stream()
