@@ -97,7 +97,7 @@ def native_conditioning(opt, gen, have):
 
 def main(argv=None):
     opt = build_parser().parse_args(argv)
-    from tweediemix_amd import i2vgen as I, ops, video as V
+    from tweediemix_amd import i2vgen as I, video as V
     cfg = I.TINY if opt.tiny else I.FULL
     h, w, Fr = opt.height // 8, opt.width // 8, opt.num_frames
     if Fr != 16:
