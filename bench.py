@@ -270,7 +270,15 @@ def main():
         # whole sample_loop with the reference's default flags (n=50, t_cond=0.2, resampling 10, jumping 5): SURVEY 8d(ii)
         from tweediemix_amd import masks as M
         imgs = M.random_rectangle_masks(K, args.res, args.res, seed=7)
-        tw.mask_provider = lambda x0: (tw.masks if S > 1 else M.build_masks(imgs, tw.h, tw.w, device))
+        if S > 1:                       # the sampler asks once per seed, in seed order: hand out that seed's mask set
+            per_seed, turn = tw.masks.clone(), [0]
+
+            def provider(x0):
+                turn[0] += 1
+                return per_seed[(turn[0] - 1) % S]
+            tw.mask_provider = provider
+        else:
+            tw.mask_provider = lambda x0: M.build_masks(imgs, tw.h, tw.w, device)
         xT = torch.randn(S, 4, tw.h, tw.w, generator=seed_gen)
         from tweediemix_amd import vae as V
         tw.vae = (V.FULL, V.synthetic_state_dict(V.FULL, device=device))     # random-init decoder of the SDXL VAE shapes
