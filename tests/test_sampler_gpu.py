@@ -354,3 +354,25 @@ def test_bench_line_contract(tmp_path):
     rf, cb = d["roofline"], d["cpu_baseline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_bench_two_ranks_control_flow(tmp_path):
+    """N>1 launch contract of bench.py (torch.distributed.run, barrier, max over ranks, result gather, ONE line from
+    rank 0).  A 1-GPU box cannot host two RCCL ranks, so both ranks share GPU 0 and rendezvous over gloo
+    (TMIX_SINGLE_GPU_DIST_TEST); everything but the backend name is the code path the driver's --gpus N run takes."""
+    need_gpu()
+    import json, subprocess, sys, socket
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(_os.environ, TMIX_SINGLE_GPU_DIST_TEST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), _os.path.join(root, "bench.py"), "--gpus", "2", "--tiny", "--res", "256", "--steps", "2",
+                        "--warmup", "1", "--cpu-threads", "4"], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # whole-job aggregate: both ranks' seeds over the slowest rank's time
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-3
