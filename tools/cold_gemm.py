@@ -24,7 +24,7 @@ def hot(d):
     for _ in range(10): lib.tmix_gemm_bf16(C.byref(d), st)
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) * 100
-for (M, N, K, cfg) in ((4096, 1280, 5120, 9), (4096, 1280, 5120, 2), (4096, 1280, 1280, 9), (4096, 10240, 1280, 9), (4096, 3840, 1280, 9)):
+for (M, N, K, cfg) in ((2048, 1280, 1280, 3), (2048, 1280, 5120, 3), (2048, 3840, 1280, 2), (2048, 10240, 1280, 7), (4096, 1280, 1280, 7), (4096, 1280, 5120, 2), (8192, 640, 640, 7), (8192, 5120, 640, 7)):
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
     out = torch.empty(M, N, device="cuda", dtype=BF)
     d = ops.make_gemm_desc(a, w, out, tile_cfg=cfg)
