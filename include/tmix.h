@@ -175,7 +175,7 @@ int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, in
 /* ws: fp32 workspace of >= tmix_groupnorm_ws_floats(B, C1+C2, groups) floats. Two inputs are
  * normalised as one tensor concatenated along C (X2 may be NULL, C2 = 0). */
 int64_t tmix_groupnorm_ws_floats(int B, int C, int groups);
-int tmix_groupnorm_ws_chunks(int64_t HW);
+int tmix_groupnorm_ws_chunks(int64_t HW);   /* statistics workgroups per image (a function of the image size only) */
 int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                         const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
                         void* stream);

@@ -43,7 +43,7 @@ def test_descriptor_layouts():
 def test_geometry_helper_without_gpu():
     from tweediemix_amd import lib
     l = lib.load()
-    assert l.tmix_groupnorm_ws_chunks(16384) == 128 and l.tmix_groupnorm_ws_chunks(16) == 1
+    assert l.tmix_groupnorm_ws_chunks(16384) == 128 and l.tmix_groupnorm_ws_chunks(1024) == 128 and l.tmix_groupnorm_ws_chunks(16) == 2 and l.tmix_groupnorm_ws_chunks(4) == 1
 
 
 def test_ops_refuse_cpu_tensors():

@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from tweediemix_amd import ops
-for (B, HW, C) in ((2, 4096, 640), (4, 4096, 640), (2, 1024, 1280), (2, 16384, 320), (2, 1024, 2560), (2, 86016, 320), (32, 5376, 320)):
+for (B, HW, C) in ((2, 16384, 320), (2, 4096, 640), (2, 1024, 1280), (1, 1024, 1280), (2, 1024, 2560), (2, 4096, 1920), (2, 16384, 960), (4, 4096, 640), (1, 16384, 512), (32, 5376, 320), (32, 1344, 640), (2, 86016, 320)):
     x = torch.randn(B, HW, C, device="cuda").to(torch.bfloat16); g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
     ws = ops.groupnorm_ws(B, C, 32, "cuda"); out = torch.empty_like(x)
     f = lambda: ops.groupnorm(x, g, b, 32, 1e-5, True, out=out, ws=ws)

@@ -23,10 +23,26 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 // ------------------------------------------------------------------------------ GroupNorm
 constexpr int GN_MAX_C = 4096;
 
+#ifndef GN_T
+#define GN_T 128
+#endif
+#ifndef GN_APPLY_U
+#define GN_APPLY_U 2
+#endif
+#ifndef GN_APPLY_ITEMS
+#define GN_APPLY_ITEMS 1024
+#endif
+#ifndef GN_APPLY_MAXB
+#define GN_APPLY_MAXB 4096
+#endif
+// statistics workgroups per image: up to GN_T, >= 8 pixels each.  A function of the image size ONLY, so the summation order
+// -- and with it every output bit -- does not depend on how many images share the launch (co-batched seeds and row-split
+// chains reproduce single runs exactly).  Measured (tools/gn_time.py): 32x32 maps want all 128 (18.1 -> 15.1 us against the
+// former HW/32 rule); a 32-image video batch would prefer 16-32 per image (-17 %) but that would tie the result to the batch.
 __host__ __device__ inline int gn_chunks(int64_t HW) {
-    int64_t c = HW / 32;
+    int64_t c = HW / 8;
+    if (c > GN_T) c = GN_T;
     if (c < 1) c = 1;
-    if (c > 128) c = 128;
     return (int)c;
 }
 
@@ -125,21 +141,33 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
     int64_t p = i0 / nvec; int v = (int)(i0 - p * nvec) + tid;      // running (pixel, vector) cursor: no 64-bit division per item
     while (v >= nvec) { v -= nvec; ++p; }
     const int step_p = 256 / nvec, step_v = 256 - step_p * nvec;
-    for (int64_t i = i0 + tid; i < i1; i += 256) {
-        const int c0 = v * 8;
-        const bf16_t* src = (c0 < C1) ? X1 + ((int64_t)b * HW + p) * C1 + c0 : X2 + ((int64_t)b * HW + p) * C2 + (c0 - C1);
-        const uint4 raw = *(const uint4*)src;
-        float f[8]; unpack8(raw, f);
+    constexpr int U = GN_APPLY_U;                        // loads in flight per thread (the pass is latency-bound)
+    for (int64_t i = i0 + tid; i < i1; i += 256 * U) {
+        uint4 raw[U]; int64_t pp[U]; int cc[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float2 k = s_ss[c0 + j];
-            float y = f[j] * k.x + k.y;
-            if (silu) y = silu_fast(y);
-            f[j] = y;
+        for (int u = 0; u < U; ++u) {
+            pp[u] = p; cc[u] = v * 8;
+            if (i + u * 256 < i1) {
+                const bf16_t* src = (cc[u] < C1) ? X1 + ((int64_t)b * HW + p) * C1 + cc[u] : X2 + ((int64_t)b * HW + p) * C2 + (cc[u] - C1);
+                raw[u] = *(const uint4*)src;
+            }
+            p += step_p; v += step_v;
+            if (v >= nvec) { v -= nvec; ++p; }
         }
-        *(uint4*)(Y + ((int64_t)b * HW + p) * C + c0) = pack8(f);
-        p += step_p; v += step_v;
-        if (v >= nvec) { v -= nvec; ++p; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i + u * 256 < i1) {
+                float f[8]; unpack8(raw[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 k = s_ss[cc[u] + j];
+                    float y = f[j] * k.x + k.y;
+                    if (silu) y = silu_fast(y);
+                    f[j] = y;
+                }
+                *(uint4*)(Y + ((int64_t)b * HW + pp[u]) * C + cc[u]) = pack8(f);
+            }
+        }
     }
 }
 
@@ -427,7 +455,7 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16_t* __restrict_
 }  // namespace
 
 extern "C" int tmix_groupnorm_ws_chunks(int64_t HW) { return gn_chunks(HW); }
-extern "C" int64_t tmix_groupnorm_ws_floats(int B, int C, int groups) { return (int64_t)B * 128 * groups * 2 + (int64_t)B * C * 2; }
+extern "C" int64_t tmix_groupnorm_ws_floats(int B, int C, int groups) { return (int64_t)B * GN_T * groups * 2 + (int64_t)B * C * 2; }
 
 extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                                    const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
@@ -443,10 +471,10 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     gn_stats_kernel<<<dim3(chunks, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, ws, HW, groups, chunks);
     TMIX_LAUNCH_CHECK();
     // ws layout: [B*chunks*groups*2] partial sums | [B*C] float2 scale/shift
-    float2* ss = (float2*)(ws + (int64_t)B * 128 * groups * 2);
+    float2* ss = (float2*)(ws + (int64_t)B * GN_T * groups * 2);
     gn_finalize_kernel<<<dim3(groups, B), 64, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
     TMIX_LAUNCH_CHECK();
-    int64_t nb = (HW * (C / 8) + 2047) / 2048; if (nb < 1) nb = 1; if (nb > 1024) nb = 1024;
+    int64_t nb = (HW * (C / 8) + GN_APPLY_ITEMS - 1) / GN_APPLY_ITEMS; if (nb < 1) nb = 1; if (nb > GN_APPLY_MAXB) nb = GN_APPLY_MAXB;
     gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
