@@ -1,6 +1,7 @@
 #!/bin/bash
 # run on the GPU box: tools/collect_profile.sh <tag>
-# (1) rocprofv3 --kernel-trace --stats of the default bench command; (2) separate PMC passes for HBM traffic.
+# (1) rocprofv3 --kernel-trace --stats of the default bench command; (2) separate PMC passes for HBM traffic;
+# (3) a PMC pass for rocprofiler's MfmaUtil (SQ_VALU_MFMA_BUSY_CYCLES summed / (GRBM_GUI_ACTIVE x SIMDs)) per kernel.
 tag=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
@@ -30,6 +31,34 @@ for k in res["FETCH_SIZE"]:
                   "launches_sampled": res["FETCH_SIZE"][k]["launches"]}
 json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(summary))
+PY
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline > $out/pmc_MFMA.log 2>&1
+python - $out $tag <<'PY'
+import csv, sys, json, collections, re
+out, tag = sys.argv[1], sys.argv[2]
+dur = {}
+try:
+    for r in csv.DictReader(open(f"{out}/{tag}_MFMA_kernel_trace.csv")):
+        dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+except Exception as e:
+    print("no kernel trace next to the counters:", e)
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f"{out}/{tag}_MFMA_counter_collection.csv")):
+    if r["Counter_Name"] != "MfmaUtil": continue
+    n = r["Kernel_Name"]
+    m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
+    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "attn_fwd" if "attn_fwd" in n else None
+    if key: agg[key].append((float(r["Counter_Value"]), dur.get(r["Dispatch_Id"], 1.0)))
+cls = collections.defaultdict(list)
+for k, v in agg.items(): cls[k.split("<")[0]] += v
+wavg = lambda v: sum(u * d for u, d in v) / sum(d for _u, d in v)
+res = {"per_kernel_class_time_weighted_percent": {k: wavg(v) for k, v in cls.items()},
+       "per_instance": {k: {"launches": len(v), "time_weighted_percent": wavg(v), "max_percent": max(u for u, _d in v),
+                            "total_ms": sum(d for _u, d in v) / 1e6} for k, v in sorted(agg.items())},
+       "note": "rocprofv3 --pmc MfmaUtil (SQ_VALU_MFMA_BUSY_CYCLES summed / (GRBM_GUI_ACTIVE x SIMDs)), eager single-stream pass of bench.py "
+               "(half-batch launches run alone, serialised by the profiler); averages weighted by kernel duration"}
+json.dump(res, open(f"{out}/{tag}_mfma_util.json", "w"), indent=1)
+print(json.dumps(res["per_kernel_class_time_weighted_percent"]))
 PY
 rm -f $out/*_kernel_trace.csv $out/*counter_collection.csv $out/*agent_info.csv
 ls $out
