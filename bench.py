@@ -64,7 +64,7 @@ def build_sampler(args, device, seed):
     tw = S.Tweediemix(conf, W, te, ts, lambda x0: M.build_masks(imgs, h, w, device), concept_num=K,
                       lora=(args.kind == "lora"), use_graphs=not args.no_graphs, n_seeds=args.seeds_per_gpu,
                       n_streams=args.streams)
-    tw.min_rows_per_stream = int(os.environ.get("TMIX_MIN_ROWS_PER_STREAM", "1"))
+    tw.min_rows_per_stream = int(os.environ.get("TMIX_MIN_ROWS_PER_STREAM", str(tw.min_rows_per_stream)))
     tw.init_fusion(int(50 * 0.2), int(50 * 0.8)) if args.kind == "lora" else tw.init_fusion(int(50 * 0.2))
     tw.masks = M.build_masks(imgs, h, w, device)
     if args.seeds_per_gpu > 1:

@@ -86,7 +86,10 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        /* the same tilings with one extra LOADER wave that issues every LDS-DMA (the math waves only read LDS and issue MFMAs) */
        TMIX_TILE_128x160_S2_LW = 8, TMIX_TILE_256x128_S3_LW = 9, TMIX_TILE_128x128_S2_LW = 10, TMIX_TILE_256x256_S2_LW = 11,
        TMIX_TILE_128x160_S4 = 12 /* tiling 7 with a 4-deep LDS ring (one workgroup per CU) */,
-       TMIX_TILE_COUNT = 12 };
+       TMIX_TILE_64x160_W5 = 13 /* five waves of 64x32, 4-deep ring: 2048 x 1280 is exactly 256 tiles (one per CU) */,
+       TMIX_TILE_256x320_S2 = 14 /* eight waves of 64x160: 2048 x 10240 (GEGLU up-projection) is exactly 256 tiles */,
+       TMIX_TILE_32x160_W5 = 15 /* five waves of 32x32: 1024 x 1280 (one batch row per chain) is 256 tiles */,
+       TMIX_TILE_COUNT = 15 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

@@ -75,5 +75,8 @@ def test_argument_errors_are_reported_before_any_launch():
     bm, bn = C.c_int(), C.c_int()
     assert l.tmix_gemm_tile_shape(9, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (256, 128)
     assert l.tmix_gemm_tile_shape(12, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (128, 160)
+    for cfg, shp in ((13, (64, 160)), (14, (256, 320)), (15, (32, 160))):
+        assert l.tmix_gemm_tile_shape(cfg, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == shp
+    assert l.tmix_gemm_tile_shape(16, C.byref(bm), C.byref(bn)) < 0 and l.tmix_gemm_stats_parts(1280, 14) == 4
     d = lib.GemmDesc()
     assert l.tmix_gemm_bf16(C.byref(d), None) < 0 and b"null" in l.tmix_last_error_string()

@@ -86,7 +86,7 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
                                    (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
 def test_gemm_plain(ops, M, N, K, cfg):
@@ -95,7 +95,7 @@ def test_gemm_plain(ops, M, N, K, cfg):
     close(out, a.float() @ w.float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
@@ -107,7 +107,7 @@ def test_gemm_epilogues(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
@@ -121,7 +121,7 @@ def test_gemm_geglu(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     Bz, M, C = 3, 100, 128
     a = rnd(Bz, M, C, seed=11)
@@ -148,7 +148,7 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 # --------------------------------------------------------------------------- conv
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 10, 6, 128, 68), (3, 8, 8, 320, 320)])
 def test_conv3x3(ops, mode, B, H, W, Cin, Cout, cfg):
@@ -278,7 +278,7 @@ def test_concat_and_embedding_and_linear_small(ops):
         torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15])
 def test_gemm_fused_layernorm_pair(ops, cfg):
     """producer GEMM emits row statistics of what it stored, consumer GEMM applies LayerNorm algebraically:
     together == Linear2(LayerNorm(Linear1(a) + res)) of diffusers' BasicTransformerBlock."""
@@ -322,7 +322,7 @@ def test_gemm_fused_layernorm_pair(ops, cfg):
     close(vt[0, :, :M], z4[:, 2 * C1:].T, rtol=2 ** -6, atol_frac=4e-3)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 7])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 7, 13])
 def test_conv_temporal_3x1x1(ops, cfg):
     """TMIX_CONV_T3 against F.conv3d with a (3,1,1) kernel and (1,0,0) padding (diffusers TemporalConvLayer):
     x [clips, frames, h*w, C] <-> torch [clips, C, frames, h, w]."""

@@ -116,10 +116,15 @@ def test_lora_merged_rows():
     torch.testing.assert_close(rows[0, :Cc], sd[f"{a1}.to_q.weight"], rtol=2 ** -7, atol=1e-3)
 
 
-def test_plan_group_row_split_matches_single_plan():
-    """PlanGroup (rows split over HIP streams) must give exactly the rows a single plan gives."""
+@pytest.mark.parametrize("force_tile", [1, 0])
+def test_plan_group_row_split_matches_single_plan(monkeypatch, force_tile):
+    """PlanGroup (rows split over HIP streams) must give the rows a single plan gives: bit for bit when both use the same
+    tiling (every kernel is batch-invariant), and to bf16 rounding when each picks its own (a chain that shares the chip
+    is tuned differently from one that runs alone, and the tiling sets the order of the LayerNorm partial sums)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if force_tile:
+        monkeypatch.setenv("TMIX_FORCE_TILE", str(force_tile))
     from tweediemix_amd import unet as U, weights as Wt
     cfg = U.TINY
     sd = Wt.synthetic_state_dict(cfg, seed=1234, nontrivial=True)
@@ -140,7 +145,10 @@ def test_plan_group_row_split_matches_single_plan():
         grp.t_dev.fill_(500.0)
         grp.run()
         torch.cuda.synchronize()
-        torch.testing.assert_close(grp.eps, ref, rtol=1e-3, atol=1e-3)
+        if force_tile:
+            assert torch.equal(grp.eps, ref)
+        else:
+            assert float((grp.eps - ref).norm() / ref.norm()) < 5e-3
 
 
 def test_full_size_sdxl_unet_vs_fp32_oracle_on_gpu():

@@ -19,8 +19,8 @@ for kind in ("custom", "lora"):
         tw, _ = bench.build_sampler(args, dev, seed=7)
         for name in ("fusion", "fusion_base", "plain", "start"):          # every phase's plan (B = K+1, K+1, 2, K+1 rows)
             pl = tw.plan(name)
-            if name == "fusion" and hasattr(pl, "refine") and seeds == 1:   # the headline configuration: re-rank under two-chain load
-                print("refined group step:", pl.refine(verbose=True), "ms", flush=True)
+            if name in ("fusion", "plain") and hasattr(pl, "refine") and seeds == 1:   # chains that share the chip: re-rank under two-chain load
+                print("refined group step:", name, pl.refine(verbose=True, top=40 if name == "fusion" else 24), "ms", flush=True)
         tw.plans.clear()
         print(kind, streams, seeds, "->", len(U._TUNE_CACHE), "shapes", flush=True)
         del tw
@@ -35,7 +35,7 @@ for hh, ww in ((56, 96), (64, 64)):
     fe, ctx, ilf = I.conditioning(Wv, torch.tensor([8.0, 8.0]), il, torch.randn(2, 1024, generator=g), torch.randn(2, 77, 1024, generator=g))
     I.I2VPlan(Wv, 2, 16, hh, ww, fe, ctx, ilf)
     grp = I.I2VPlanGroup(Wv, 2, 16, hh, ww, fe, ctx, ilf)              # run_video's default: one chain per clip
-    print("refined video step:", grp.refine(verbose=True, reps=5), "ms", flush=True)
+    print("refined video step:", grp.refine(verbose=True, reps=5, top=30), "ms", flush=True)
     del grp
     print("video", hh, ww, "->", len(U._TUNE_CACHE), "shapes", flush=True)
     torch.cuda.empty_cache()

@@ -71,7 +71,10 @@ gemm_conv_kernel(const Params p) {
     constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
     constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
     constexpr int SW = LW ? 1 : NW;                    // waves that share the staging of a K-tile
-    constexpr int RA = BM / 8 / SW, RB = BN / 8 / SW;  // LDS-DMA instructions per staging wave per stage
+    constexpr int IA = BM / 8, IB = BN / 8;            // LDS-DMA instructions per stage (8 rows of 128 bytes each)
+    // ... per staging wave; when the waves do not divide them (64x160 over 5 waves) a surplus slot re-stages the last rows
+    // (same bytes to the same place), so every wave issues the same count and the counted vmcnt waits stay valid
+    constexpr int RA = (IA + SW - 1) / SW, RB = (IB + SW - 1) / SW;
     constexpr int L = RA + RB;
     static_assert(RA >= 1 && RB >= 1 && FM >= 1 && FN >= 1, "tile/wave geometry");
     static_assert((NS - 2) * L <= 63, "vmcnt immediate");
@@ -108,6 +111,8 @@ gemm_conv_kernel(const Params p) {
     // per-lane offsets are 32-bit element counts off wave-uniform bases (saddr + voffset form of global_load_lds)
     // A loader wave (LW) covers ALL rows of the tile; its per-lane offsets follow from two parity variants (the swizzle
     // of instruction idx depends on idx & 1 only) plus a wave-uniform row advance, clamped like the per-wave arrays below.
+    auto slot_a = [&](int r) { int i = r * SW + sw_id; if constexpr (IA % SW != 0) i = min(i, IA - 1); return i; };
+    auto slot_w = [&](int r) { int i = r * SW + sw_id; if constexpr (IB % SW != 0) i = min(i, IB - 1); return i; };
     constexpr int RAa = (LW && !CONV) ? 1 : RA, RBa = LW ? 1 : RB;
     unsigned woff[RBa], aoff[RAa];
     int pb[CONV ? RA : 1], py[CONV ? RA : 1], px[CONV ? RA : 1], asw[(CONV && !LW) ? RA : 1];
@@ -137,14 +142,14 @@ gemm_conv_kernel(const Params p) {
     if (stager) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        const int idx = r * SW + sw_id;
+        const int idx = slot_w(r);
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
         int n = n0 + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
         woff[r] = ((unsigned)n * (unsigned)p.ldw + sw) * 2u;
     }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-        const int idx = r * SW + sw_id;
+        const int idx = slot_a(r);
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;
         int m = m0 + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
         asw[r] = sw;
@@ -188,16 +193,16 @@ gemm_conv_kernel(const Params p) {
         char* sW = sA + A_TILE;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + (r * SW + sw_id) * 1024);
+            if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + slot_a(r) * 1024);
             else if constexpr (LW) blds16(rsA, min(aoffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.lda), amaxp[r & 1]),
                                           (unsigned)kt * (BK * 2), sA + r * 1024);
-            else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + (r * SW + sw_id) * 1024);
+            else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             if constexpr (LW) blds16(rsW, min(woffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.ldw), wmaxp[r & 1]),
                                      (unsigned)kt * (BK * 2), sW + r * 1024);
-            else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + (r * SW + sw_id) * 1024);
+            else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
         }
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < p.ntaps) conv_tap_offsets(); } }
     };
@@ -556,7 +561,13 @@ struct TileCfg { int bm, bn; };
 // with 128-wide wave tiles (5, 6) have no registers for a fifth wave on one of the SIMDs
 // 12 = tiling 7 (128x160) with a 4-deep ring (one workgroup per CU, three K-tiles in flight: the in-sequence loop is bound by
 // memory latency x bytes in flight, and 160-wide tiles divide N = 1280 / 640 exactly)
-constexpr int NUM_CFG = 12;
+// 13 = 64x160 over FIVE waves (each 64x32), 4-deep ring: 2048 x 1280 -- the half-batch launches of the 32x32 level -- is
+// exactly 256 tiles, one per CU, where 128x128 leaves 96 CUs idle (160 tiles) and 128x160 half of them
+// 14 = 256x320 over eight waves (wave tile 64x160): the GEGLU up-projection 2048 x 10240 is exactly 256 tiles, where
+// 256x256 runs 320 (a quarter-full second round); 128x320 over four waves was tried and lost to 128x160 everywhere
+// 15 = 32x160 over five waves (each 32x32): 1024 x 1280 -- one batch row per chain, the CFG-pair calls -- is 256 tiles
+// (a 5-deep ring for 13 measured the same as the 4-deep one)
+constexpr int NUM_CFG = 15;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -588,7 +599,7 @@ template <int CONV>
 int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
     if (p.n_trans_begin >= 0) {                                                // transposed stores need square wave tiles
-        if (cfg == 4 || cfg == 5 || cfg == 7 || cfg == 12) cfg = 2;
+        if (cfg == 4 || cfg == 5 || cfg == 7 || cfg >= 12) cfg = 2;
         if (cfg == 6 && (p.n_trans_begin % 256)) cfg = 2;                     // the boundary must fall on a tile edge (N = 3 x 320: 640)
         if (cfg == 8 || cfg == 11) cfg = 9;
     }
@@ -601,6 +612,9 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
     case 6: return launch_cfg<256, 256, 2, 2, 2, CONV>(p, batch, st);
     case 7: return launch_cfg<128, 160, 4, 1, 2, CONV>(p, batch, st);
     case 12: return launch_cfg<128, 160, 4, 1, 4, CONV>(p, batch, st);
+    case 13: return launch_cfg<64, 160, 1, 5, 4, CONV>(p, batch, st);
+    case 14: return launch_cfg<256, 320, 4, 2, 2, CONV>(p, batch, st);
+    case 15: return launch_cfg<32, 160, 1, 5, 4, CONV>(p, batch, st);
     default: break;
     }
     // loader-wave variants exist for the plain GEMM only: the im2col gather's per-row offset tables do not fit the loader's
@@ -627,7 +641,7 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
 
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
-                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}};
+                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

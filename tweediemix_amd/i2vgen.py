@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import lib as L
 from . import ops
-from .unet import UNetPlan, _Arena, BF16, F32, refine_group
+from .unet import UNetPlan, _Arena, BF16, F32, refine_group, SHARED as U_SHARED
 from .weights import fold_layernorm, interleave_geglu
 
 
@@ -208,8 +208,9 @@ class I2VPlan(UNetPlan):
     INJECT_SITES = {"mid_block.resnets.0": True, "mid_block.resnets.1": True, "up_blocks.1.resnets.0": False}   # site -> hard copy?
 
     def __init__(self, W: I2VWeights, clips: int, frames: int, h: int, w: int, fps_emb, context, il_feat, autotune: bool = True,
-                 interp: float = 0.7):
+                 interp: float = 0.7, shared: bool = False):
         cfg = W.cfg
+        self.tune_ctx = U_SHARED if shared else ""
         self.inject, self.interp = False, interp         # raised per step by the sampling loop (FeatureInjector schedule)
         self.W, self.cfg, self.clips, self.frames, self.h, self.w = W, cfg, clips, frames, h, w
         self.B = B = clips * frames                     # spatial layers see every frame as one image
@@ -428,7 +429,7 @@ class I2VPlanGroup:
     def __init__(self, W: I2VWeights, clips: int, frames: int, h: int, w: int, fps_emb, context, il_feat, autotune: bool = True,
                  interp: float = 0.7):
         self.cfg, self.clips, self.frames, self.h, self.w = W.cfg, clips, frames, h, w
-        self.plans = [I2VPlan(W, 1, frames, h, w, fps_emb[i:i + 1], context[i:i + 1], il_feat[i:i + 1], autotune=autotune, interp=interp)
+        self.plans = [I2VPlan(W, 1, frames, h, w, fps_emb[i:i + 1], context[i:i + 1], il_feat[i:i + 1], autotune=autotune, interp=interp, shared=clips > 1)
                       for i in range(clips)]
         self.streams = [None] + [torch.cuda.Stream(device=W.device) for _ in range(clips - 1)]
         self.eps = torch.zeros(clips * frames, W.cfg.out_channels, h, w, device=W.device, dtype=F32)

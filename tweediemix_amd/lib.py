@@ -15,8 +15,9 @@ F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
 CONV_S1, CONV_S2, CONV_UP2, CONV_T3, CONV_S2A = 0, 1, 2, 3, 4
-TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 12, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
-TILE_CANDIDATES = (1, 2, 3, 4, 5, 6, 7, 12)                  # what the autotuner times by default
+TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 15, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
+TILE_CANDIDATES = (1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15)                  # what the autotuner times by default
+TILE_EXCLUSIVE = (13, 14, 15)                                  # one workgroup per CU over the whole chip: not beside a sibling chain
 TILE_LW = (8, 9, 10, 11)                                     # added with TMIX_TUNE_LW=1 (GEMM only)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

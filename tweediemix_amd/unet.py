@@ -256,6 +256,12 @@ class _Arena:
 
 
 _TUNE_CACHE = {}      # repr((kind, shape key)) -> best TMIX_TILE_* id, shared by every plan in the process
+# The same launch wants a different tiling when its chain has the chip to itself than when a sibling chain runs beside it
+# (PlanGroup): alone, the tilings that put exactly one workgroup on each of the 256 CUs win by 15-35 % (L.TILE_EXCLUSIVE:
+# 64x160 / 32x160 over five waves, 256x320); next to another chain those own every CU while they run and whole steps come
+# out 3 % slower than with 128x128 / 128x160 grids that leave CUs to the sibling.  Entries measured for a chain that shares
+# the chip carry this prefix; a shape without one falls back to the plain entry unless that is an exclusive tiling.
+SHARED = "shared|" 
 _TUNE_FILE = os.environ.get("TMIX_TUNE_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json"))
 
 
@@ -287,8 +293,9 @@ class UNetPlan:
 
     def __init__(self, W: UNetWeights, B: int, h: int, w: int, kv: KVCache, pooled: torch.Tensor,
                  time_ids: torch.Tensor, routed: bool = False, autotune: bool = True, row_sets=None,
-                 latent=None, eps=None):
+                 latent=None, eps=None, shared: bool = False):
         self.W, self.cfg, self.B, self.h, self.w = W, W.cfg, B, h, w
+        self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
         # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
         self.row_sets = list(row_sets) if row_sets is not None else list(range(B))
@@ -356,7 +363,16 @@ class UNetPlan:
             self._link_ln()
             return
         keys = [self._tune_key(kind, d) for _i, kind, d in tun]
-        if any(k not in _TUNE_CACHE for k in keys):
+        ctx = getattr(self, "tune_ctx", "")
+
+        def lookup(k):
+            c = _TUNE_CACHE.get(ctx + k)
+            if c is None and ctx:
+                c = _TUNE_CACHE.get(k)
+                if c in L.TILE_EXCLUSIVE:
+                    c = None
+            return c
+        if any(lookup(k) is None for k in keys):
             idx = {i: n for n, (i, _k, _d) in enumerate(tun)}
             st = torch.cuda.current_stream().cuda_stream
             best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
@@ -386,11 +402,13 @@ class UNetPlan:
                     for k, t in tot.items():
                         best_t[(k, cfg)] = min(best_t.get((k, cfg), float("inf")), t)
             for k in set(keys):
+                ok = [c for c in cands if k.startswith("('gemm'") or c not in L.TILE_LW]
                 if k not in _TUNE_CACHE:
-                    ok = [c for c in cands if k.startswith("('gemm'") or c not in L.TILE_LW]
                     _TUNE_CACHE[k] = min(ok, key=lambda c: best_t[(k, c)])
+                if SHARED + k not in _TUNE_CACHE:     # starting point for chains that share the chip (refine_group re-ranks under load)
+                    _TUNE_CACHE[SHARED + k] = min([c for c in ok if c not in L.TILE_EXCLUSIVE], key=lambda c: best_t[(k, c)])
         for (_i, _kind, d), k in zip(tun, keys):
-            d.tile_cfg = _TUNE_CACHE[k]
+            d.tile_cfg = lookup(k)
         self._link_ln()
         torch.cuda.synchronize()
 
@@ -698,7 +716,7 @@ def refine_group(self, top=14, reps=9, verbose=False):
             p._link_ln()
         if verbose:
             print(f"  refine {k}: {cur} -> {best}  ({base:.3f} -> {best_t:.3f} ms)", flush=True)
-        _TUNE_CACHE[k] = best
+        _TUNE_CACHE[getattr(members[k][0][0], "tune_ctx", "") + k] = best
         base = best_t
     return base
 
@@ -727,7 +745,7 @@ class PlanGroup:
             kv = KVCache(W, ehs[sl], list(wsel)[sl])
             self.plans.append(UNetPlan(W, per, h, w, kv, pooled[sl], time_ids[sl], routed=routed,
                                        row_sets=list(wsel)[sl] if routed else None,
-                                       latent=self.latent[sl], eps=self.eps[sl]))
+                                       latent=self.latent[sl], eps=self.eps[sl], shared=n_groups > 1))
             self.streams.append(torch.cuda.Stream(device=dev) if g > 0 else None)
         self.t_dev = _FillAll([p.t_dev for p in self.plans])
         self.flops = sum(p.flops for p in self.plans)
