@@ -153,3 +153,25 @@ def test_video_image_preprocessing_matches_reference_vectors(golden_dir):
     assert np.array_equal(got.numpy(), z["pil.out"])
     pv = V.clip_pixel_values(img)
     assert pv.shape == (1, 3, 90, 150) and abs(float(pv.mean())) < 3
+
+
+def test_tile_table_contexts():
+    """a chain that shares the chip reads its own entry, falls back to the plain one, and never inherits a
+    one-workgroup-per-CU tiling; the shipped table holds both contexts for the headline launch shapes."""
+    from tweediemix_amd import unet as U, lib as L
+    saved = dict(U._TUNE_CACHE)
+    try:
+        U._TUNE_CACHE.clear()
+        U._TUNE_CACHE.update({"a": 3, U.SHARED + "a": 2, "b": 7, "c": L.TILE_EXCLUSIVE[0]})
+        assert U.tune_lookup("", "a") == 3 and U.tune_lookup(U.SHARED, "a") == 2
+        assert U.tune_lookup("", "b") == 7 and U.tune_lookup(U.SHARED, "b") == 7
+        assert U.tune_lookup("", "c") == L.TILE_EXCLUSIVE[0] and U.tune_lookup(U.SHARED, "c") is None
+        assert U.tune_lookup("", "missing") is None and U.tune_lookup(U.SHARED, "missing") is None
+    finally:
+        U._TUNE_CACHE.clear()
+        U._TUNE_CACHE.update(saved)
+    ff1 = "('gemm', 2048, 10240, 1280, 1, 1, False, False, False, False, True)"      # GEGLU up-projection of a two-row chain
+    assert U.tune_lookup("", ff1) in L.TILE_CANDIDATES and U.tune_lookup(U.SHARED, ff1) in L.TILE_CANDIDATES
+    assert all(1 <= v <= L.TILE_COUNT for v in U._TUNE_CACHE.values())
+    assert set(L.TILE_EXCLUSIVE) <= set(L.TILE_CANDIDATES)
+

@@ -281,6 +281,18 @@ def save_tune_table(path):
         json.dump(dict(sorted(_TUNE_CACHE.items())), f, indent=0)
 
 
+def tune_lookup(ctx, key):
+    """tiling for launch shape `key` in context `ctx` ("" = the chain has the chip to itself, SHARED = a sibling chain runs
+    beside it), or None when it must be measured: a shared chain falls back to the plain entry (tables written before the
+    contexts existed) unless that entry is a one-workgroup-per-CU tiling, which must not be inherited."""
+    c = _TUNE_CACHE.get(ctx + key)
+    if c is None and ctx:
+        c = _TUNE_CACHE.get(key)
+        if c in L.TILE_EXCLUSIVE:
+            c = None
+    return c
+
+
 load_tune_table()
 
 
@@ -364,14 +376,7 @@ class UNetPlan:
             return
         keys = [self._tune_key(kind, d) for _i, kind, d in tun]
         ctx = getattr(self, "tune_ctx", "")
-
-        def lookup(k):
-            c = _TUNE_CACHE.get(ctx + k)
-            if c is None and ctx:
-                c = _TUNE_CACHE.get(k)
-                if c in L.TILE_EXCLUSIVE:
-                    c = None
-            return c
+        lookup = lambda k: tune_lookup(ctx, k)
         if any(lookup(k) is None for k in keys):
             idx = {i: n for n, (i, _k, _d) in enumerate(tun)}
             st = torch.cuda.current_stream().cuda_stream
