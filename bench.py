@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- denoise steps/sec of the Tweedie-mix fusion phase on MI355X.
+"""bench.py -- denoise steps/sec of the Tweedie-mix fusion phase on MI355X (+ images/sec of whole trajectories).
 
-A "step" = one fusion-phase iteration of `sample_loop` (fusion_sampling.py:493-494 with
-t <= t_cond_cur): ONE SDXL UNet forward at batch K+1 (uncond + K concept rows, per-concept
-weights routed) + the fused CFG/Tweedie/blend/DDIM kernel, latent resident in HBM.
-Workload (BASELINE.json configs[1]): SDXL-base shapes, 1024x1024 (latent 128x128), K=3 concepts
-(2 foreground + background), Custom-Diffusion K/V deltas (`--kind lora` = configs[2]), synthetic
-random-init weights / prompt embeddings / rectangle masks (no checkpoints exist offline).
+A "step" = one fusion-phase iteration of `sample_loop` (fusion_sampling.py:493-494 with t <= t_cond_cur): ONE SDXL UNet
+forward at batch K+1 (uncond + K concept rows, per-concept weights routed) + the fused CFG/Tweedie/blend/DDIM kernel,
+replayed as one hipGraph with the latent resident in HBM.
+Workload: SDXL-base shapes, 1024x1024 (latent 128x128), K=3 concepts (2 foreground + background), synthetic random-init
+weights / prompt embeddings / rectangle masks (no checkpoints exist offline).  `--kind lora` (default, BASELINE.json
+configs[2], the north-star headline: merged per-row LoRA weights, --t_stop 0.8) or `--kind custom` (configs[1]); with the
+default `--kind both` the line's `value` is the LoRA figure and `other_configs.custom` carries configs[1].
 
-python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+  python bench.py --gpus N --steps K --warmup W
+N > 1 without a launcher: the script starts its own N ranks (tweediemix_amd/launch.py; one process per GPU, RCCL); under
+`python -m torch.distributed.run` it uses the ranks it is given.  Rank 0 prints ONE JSON line: the contract fields plus
+`roofline` (timed IN SITU: every GEMM / conv / attention / GroupNorm launch of the captured step records its own
+start / end on the device clock while the graph replays), `images_per_s` (whole 50-step trajectories incl. the VAE
+decode, all ranks), `parity_check` and, at N = 1, `cpu_baseline`.
 """
 import argparse
 import json
@@ -17,7 +22,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,151 +29,207 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+METRIC = "denoise steps/sec @ SDXL 1024^2 K=3 concepts (fusion phase); images/sec at 1/2/4/8 GPUs"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--kind", default="custom", choices=["custom", "lora"])
+    ap.add_argument("--kind", default="both", choices=["both", "lora", "custom"])
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (debug only; not a valid bench line)")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--trajectory", action="store_true",
-                    help="extra line: time whole 50-step trajectories (start/resampling, plain, jumping, fusion: 75 UNet calls)")
+    ap.add_argument("--no-trajectory", action="store_true", help="skip the whole-trajectory / images-per-second part")
     ap.add_argument("--streams", type=int, default=2, help="independent launch chains per UNet call (rows split over HIP streams)")
     ap.add_argument("--seeds-per-gpu", type=int, default=1,
                     help="independent trajectories co-batched into every UNet launch (1 = the reference's one image per process)")
+    ap.add_argument("--num-seeds", type=int, default=0,
+                    help="BASELINE config 4: this many seeds in total, sharded round-robin over the ranks (0: seeds-per-gpu per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64)
-    ap.add_argument("--cpu-rows", type=int, default=1, help="batch rows of one fusion step timed on the CPU")
-    return ap.parse_args()
+    ap.add_argument("--host-dry-run", action="store_true",
+                    help="launcher / collective control flow only, on CPU over gloo with a stand-in step (tests; NOT a bench line)")
+    return ap.parse_args(argv)
 
 
-def build_sampler(args, device, seed):
+# ------------------------------------------------------------------------------------------------ sampler construction
+def build_sampler(args, kind, device, seed):
     from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
     cfg = U.TINY if args.tiny else U.SDXL
     K = 3
     sd = Wt.synthetic_state_dict(cfg, seed=1234, device=device, dtype=torch.bfloat16)
-    con = Wt.synthetic_concepts(cfg, args.kind, K, device=device)
-    W = U.UNetWeights(cfg, sd, device, (args.kind, con))
+    con = Wt.synthetic_concepts(cfg, kind, K, device=device)
+    W = U.UNetWeights(cfg, sd, device, (kind, con))
     g = torch.Generator(device="cpu").manual_seed(42)
     te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g), torch.randn(K + 2, cfg.pooled_dim, generator=g))
     ts = (torch.randn(K, 77, cfg.cross_dim, generator=g), torch.randn(K, cfg.pooled_dim, generator=g))
     h = w = args.res // 8
-    imgs = M.random_rectangle_masks(K, args.res, args.res, seed=seed)
+    S_ = args.seeds_per_gpu
     conf = S.make_config(guidance_scale=0.8, n_timesteps=50, t_cond=0.2, t_stop=0.8, resampling_steps=10,
                          jumping_steps=5, resolution_h=args.res, resolution_w=args.res, seed=seed)
-    tw = S.Tweediemix(conf, W, te, ts, lambda x0: M.build_masks(imgs, h, w, device), concept_num=K,
-                      lora=(args.kind == "lora"), use_graphs=not args.no_graphs, n_seeds=args.seeds_per_gpu,
-                      n_streams=args.streams)
+
+    def mask_set(i):
+        return M.build_masks(M.random_rectangle_masks(K, args.res, args.res, seed=1000 * seed + i), h, w, device)
+
+    turn = [0]
+
+    def provider(x0):                       # the sampler asks once per seed, in seed order
+        turn[0] += 1
+        return mask_set((turn[0] - 1) % S_)
+
+    tw = S.Tweediemix(conf, W, te, ts, provider, concept_num=K, lora=(kind == "lora"), use_graphs=not args.no_graphs,
+                      n_seeds=S_, n_streams=args.streams)
     tw.min_rows_per_stream = int(os.environ.get("TMIX_MIN_ROWS_PER_STREAM", str(tw.min_rows_per_stream)))
-    tw.init_fusion(int(50 * 0.2), int(50 * 0.8)) if args.kind == "lora" else tw.init_fusion(int(50 * 0.2))
-    tw.masks = M.build_masks(imgs, h, w, device)
-    if args.seeds_per_gpu > 1:
-        tw.masks = torch.stack([M.build_masks(M.random_rectangle_masks(K, args.res, args.res, seed=1000 * seed + i), h, w, device)
-                                for i in range(args.seeds_per_gpu)]).contiguous()
+    tw.init_fusion(int(50 * 0.2), int(50 * 0.8)) if kind == "lora" else tw.init_fusion(int(50 * 0.2))
+    tw.masks = mask_set(0) if S_ == 1 else torch.stack([mask_set(i) for i in range(S_)]).contiguous()
     return tw, (sd, con, te, ts, cfg)
 
 
-def gemm_roofline(plan):
-    """per-launch HIP-event timing of the dominant kernel (gemm_conv_kernel<..,0>, the bf16 MFMA GEMM) inside
-    one eager single-stream forward of the SAME launches the timed region replays:
-    achieved = sum(algorithmic flops) / sum(launch durations)."""
-    import ctypes as C
+def fusion_timesteps(tw):
+    return [t for t in tw.scheduler.timesteps if t <= tw.t_cond_cur and t in tw._window]
+
+
+def timed_fusion_steps(tw, args, world, device, x):
+    """W warm-up + K timed fusion steps (barrier + synchronize on both sides).  Returns (seconds, final latent)."""
+    from tweediemix_amd import lib as L
+    ts = fusion_timesteps(tw)
+    tw.x_state.copy_(x)
+
+    def step(i):
+        t = ts[i % len(ts)]
+        tw._run_step("fusion", L.STEP_FUSION, t, tw.alpha(t), tw.alpha(t - tw.skip))
+
+    for i in range(max(args.warmup, 2)):        # the first call builds the plan, the second captures the graph
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(tw.x_state).all()
+    return dt, tw.x_state.clone()
+
+
+def parity_check(tw, args, parts, kind, device):
+    """the timed path (hipGraph replay, two launch chains, shipped tile table) against an eager single-chain run of the SAME
+    step from the same latent: rel-L2 of the updated latent (the tilings differ, so LayerNorm partial sums are added in a
+    different order: equal to bf16 rounding, not bit for bit)."""
+    from tweediemix_amd import lib as L, sampler as S
+    t = fusion_timesteps(tw)[3]
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(tw.n_seeds, 4, tw.h, tw.w, generator=g).to(device)
+    tw.x_state.copy_(x)
+    tw._run_step("fusion", L.STEP_FUSION, t, tw.alpha(t), tw.alpha(t - tw.skip))
+    got = tw.x_state.clone()
+    ref = S.Tweediemix(tw.config, tw.W, tw.text_embeds, tw.text_embeds_single, tw.mask_provider, concept_num=tw.concept_num,
+                       lora=tw.lora, use_graphs=False, n_seeds=tw.n_seeds, n_streams=1)
+    ref.init_fusion(int(50 * 0.2), int(50 * 0.8)) if kind == "lora" else ref.init_fusion(int(50 * 0.2))
+    ref.masks = tw.masks
+    ref.x_state.copy_(x)
+    ref._run_step("fusion", L.STEP_FUSION, t, ref.alpha(t), ref.alpha(t - ref.skip))
+    want = ref.x_state
+    rel = float((got - want).norm() / want.norm())
+    del ref
+    assert rel < 2e-2, f"timed path differs from the eager single-chain run: rel L2 {rel}"
+    return {"vs": "eager single-chain run of the same step (no graph, one stream)", "rel_l2": rel, "tol": 2e-2}
+
+
+# ------------------------------------------------------------------------------------------------ in-situ roofline
+def insitu_profile(tw, reps=3):
+    """per-launch device-clock timing of the captured fusion step, in the schedule the timed region replays.
+    Returns per-class totals of the median replay: launches, sum of launch durations, union busy time, flops."""
+    import collections
     from tweediemix_amd import lib as L
     lib = L.load()
-    st = torch.cuda.current_stream().cuda_stream
-    gemm_fn = lib.tmix_gemm_bf16
-    conv_fn = lib.tmix_conv3x3_nhwc
-    attn_fn = lib.tmix_attn_fwd
-    fl_by = {"gemm": [f for _d, f in plan.launches["gemm"]], "conv": [f for _d, f in plan.launches["conv"]],
-             "attn": [f for _a, f in plan.launches["attn"]]}
-    ev = {"gemm": [], "conv": [], "attn": []}
-    plan.run()
-    torch.cuda.synchronize()
-    if hasattr(plan, "plans"):          # PlanGroup: the instrumented pass runs the sub-plans back to back on one stream
-        pass
-    for fn, a in plan.ops:
-        key = "gemm" if fn is gemm_fn else "conv" if fn is conv_fn else "attn" if fn is attn_fn else None
-        if key:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        rc = fn(*a, st)
-        assert rc == 0
-        if key:
-            e1.record()
-            ev[key].append((e0, e1))
-    torch.cuda.synchronize()
-    if os.environ.get("TMIX_BENCH_SHAPES"):
-        import collections
-        agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-        for (d, fl), (a, b) in zip(plan.launches["gemm"], ev["gemm"]):
-            k = ("gemm", d.batch, d.M, d.N, d.K, "geglu" if d.epilogue else "", "T" if d.n_trans_begin >= 0 else "", d.tile_cfg)
-            agg[k][0] += 1; agg[k][1] += a.elapsed_time(b); agg[k][2] += fl
-        for (d, fl), (a, b) in zip(plan.launches["conv"], ev["conv"]):
-            k = ("conv", d.B, d.H, d.W, d.Cin, d.Cout, d.mode, d.tile_cfg)
-            agg[k][0] += 1; agg[k][1] += a.elapsed_time(b); agg[k][2] += fl
-        for (args, fl), (a, b) in zip(plan.launches["attn"], ev["attn"]):
-            k = ("attn", args[12], args[13], args[14], args[15])
-            agg[k][0] += 1; agg[k][1] += a.elapsed_time(b); agg[k][2] += fl
-        for k, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print(f"  {str(k):60s} n={n:4d} total={ms:7.3f}ms avg={1e3 * ms / n:7.1f}us {fl / ms / 1e9:6.0f}TF", file=sys.stderr)
-    out = {}
-    # algorithmic HBM bytes of a GEMM launch: A and W read once, C written once, residual read once (bf16), GEGLU halves C
+    plan = tw.plan("fusion")
+    meta = plan.issued_meta()
+    n = len(meta)
+    slots = torch.zeros(n, 8, dtype=torch.int64, device=tw.device)
+    init = torch.zeros(n, 8, dtype=torch.int64)
+    init[:, 0] = -1                                     # UINT64_MAX
+    init = init.to(tw.device)
+    L.check(lib.tmix_prof_begin(slots.data_ptr(), n), "tmix_prof_begin")
+    try:
+        if tw.use_graphs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                tw._enqueue_step("fusion", L.STEP_FUSION)
+            run = g.replay
+        else:
+            run = None
+    finally:
+        used = lib.tmix_prof_end()
+    if run is None:                                     # eager mode: instrument every run
+        def run():
+            lib.tmix_prof_begin(slots.data_ptr(), n)
+            tw._enqueue_step("fusion", L.STEP_FUSION)
+            lib.tmix_prof_end()
+    else:
+        assert used == n, (used, n)
+    runs = []
+    for _ in range(reps + 1):
+        slots.copy_(init)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run()
+        e1.record()
+        torch.cuda.synchronize()
+        runs.append((e0.elapsed_time(e1), slots.cpu().numpy().astype("uint64")))
+    runs = sorted(runs[1:], key=lambda r: r[0])
+    wall_ms, sl = runs[len(runs) // 2]
+    tick = 1e-5                                         # ms per tick of the 100 MHz clock
+    by = collections.defaultdict(lambda: dict(launches=0, sum_ms=0.0, flops=0.0, iv=[]))
+    shapes = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for (cls, fl, key), s in zip(meta, sl):
+        d = (int(s[1]) - int(s[0])) * tick
+        c = by[cls]
+        c["launches"] += 1; c["sum_ms"] += d; c["flops"] += fl; c["iv"].append((int(s[0]), int(s[1])))
+        if os.environ.get("TMIX_BENCH_SHAPES"):
+            k = key if isinstance(key, tuple) else ((cls, key.batch, key.M, key.N, key.K, key.epilogue, key.tile_cfg) if cls == "gemm"
+                                                     else (cls, key.B, key.H, key.W, key.Cin, key.Cout, key.mode, key.tile_cfg))
+            shapes[k][0] += 1; shapes[k][1] += d; shapes[k][2] += fl
+    for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {str(k):64s} n={cnt:4d} total={ms:7.3f}ms avg={1e3 * ms / cnt:7.1f}us {fl / ms / 1e9 if ms else 0:6.0f}TF", file=sys.stderr)
+
+    def union(iv):
+        tot, end = 0, -1
+        for a, b in sorted(iv):
+            if b <= end:
+                continue
+            tot += b - max(a, end)
+            end = b
+        return tot * tick
+
+    out = {"replay_ms": wall_ms}
+    all_iv = []
+    for cls, c in by.items():
+        all_iv += c["iv"]
+        out[cls] = dict(launches=c["launches"], sum_launch_ms=c["sum_ms"], busy_ms=union(c["iv"]),
+                        avg_launch_us=1e3 * c["sum_ms"] / max(1, c["launches"]), flops=c["flops"],
+                        tflops=c["flops"] / max(1e-9, c["sum_ms"]) / 1e9)
+    out["instrumented_busy_ms"] = union(all_iv)
+    return out
+
+
+def gemm_alg_bytes(plan):
+    """algorithmic HBM bytes of the GEMM launches: A and W read once, C written once, residual read once (bf16); GEGLU halves C."""
+    from tweediemix_amd import lib as L
     gb = 0
     for d, _f in plan.launches["gemm"]:
         n_out = d.N // 2 if d.epilogue == L.EPI_GEGLU else d.N
         wsets = d.batch if d.strideW else 1
         gb += 2 * (d.batch * d.M * d.K + wsets * d.N * d.K + d.batch * d.M * n_out + (d.batch * d.M * d.N if d.residual else 0))
-    for key in ev:
-        ms = [a.elapsed_time(b) for a, b in ev[key]]
-        out[key] = dict(launches=len(ms), total_ms=float(sum(ms)), avg_us=float(1e3 * sum(ms) / max(1, len(ms))),
-                        tflops=float(sum(fl_by[key]) / max(1e-9, sum(ms)) / 1e9), flops=float(sum(fl_by[key])))
-    out["gemm"]["alg_bytes_per_launch"] = gb / max(1, len(plan.launches["gemm"]))
-    return out
-
-
-def gemm_concurrent(plan, reps=3):
-    """GEMM launches only, replayed the way the timed region runs them (one chain per HIP stream, concurrently):
-    aggregate TFLOP/s = sum(flops) / wall.  Complements `roofline.achieved`, which times each launch alone."""
-    from tweediemix_amd import lib as L
-    lib = L.load()
-    subs = plan.plans if hasattr(plan, "plans") else [plan]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in subs[1:]]
-    lists = [[(fn, a) for fn, a in p.ops if fn is lib.tmix_gemm_bf16] for p in subs]
-    flops = sum(f for p in subs for _d, f in p.launches["gemm"])
-    def enqueue():
-        fork = torch.cuda.Event(); fork.record()
-        joins = []
-        for ops_, st in zip(lists, streams):
-            st.wait_event(fork)
-            with torch.cuda.stream(st):
-                for fn, a in ops_:
-                    fn(*a, st.cuda_stream)
-                ev = torch.cuda.Event(); ev.record(st); joins.append(ev)
-        for ev in joins:
-            torch.cuda.current_stream().wait_event(ev)
-
-    # captured once and replayed, like the timed region: eager launches from Python (~20 us each) would serialise the chains
-    enqueue()
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        streams[0] = torch.cuda.current_stream()
-        enqueue()
-    best = None
-    for _ in range(reps):
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        best = ms if best is None else min(best, ms)
-    return {"tflops": flops / best / 1e9, "ms": best, "streams": len(subs)}
+    return gb / max(1, len(plan.launches["gemm"]))
 
 
 def pmc_traffic():
@@ -186,37 +246,153 @@ def pmc_traffic():
         return None
 
 
+# ------------------------------------------------------------------------------------------------ trajectories
+def run_trajectories(tw, args, rank, world, device):
+    """whole sample_loop runs with the reference's default flags (n=50, t_cond=0.2, resampling 10, jumping 5: 75 UNet calls)
+    + the final VAE decode.  --num-seeds T: the T seeds are sharded round-robin over the ranks and co-batched
+    seeds-per-gpu at a time (BASELINE config 4); otherwise every rank runs seeds-per-gpu seeds (weak scaling)."""
+    from tweediemix_amd import dist as D, vae as V
+    S_ = tw.n_seeds
+    if args.num_seeds:
+        mine = D.seed_shard(list(range(args.num_seeds)), rank, world)
+        total = args.num_seeds
+    else:
+        mine = [rank * S_ + i for i in range(S_)]
+        total = world * S_
+    vcfg = V.TINY if args.tiny else V.FULL
+    tw.vae = (vcfg, V.synthetic_state_dict(vcfg, device=device))     # random-init decoder of the SDXL VAE shapes
+
+    def noise(seed_ids):
+        xs = [torch.randn(1, 4, tw.h, tw.w, generator=torch.Generator().manual_seed(7000 + s)) for s in seed_ids]
+        return torch.cat(xs)
+
+    batches = [mine[i:i + S_] for i in range(0, len(mine), S_)]
+    tw.unet_calls.clear()
+    warm = tw.run_fusion(noise((batches[0] + batches[0] * S_)[:S_]) if batches else noise(list(range(S_))), decode=True)
+    assert torch.isfinite(warm).all()
+    n_calls = len(tw.unet_calls)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t1 = time.perf_counter()
+    lats, t_loop = [], 0.0
+    for b in batches:
+        ids = (b + b * S_)[:S_]                       # a ragged last batch is padded with repeats and trimmed afterwards
+        tl = time.perf_counter()
+        lat = tw.run_fusion(noise(ids))
+        torch.cuda.synchronize()
+        t_loop += time.perf_counter() - tl
+        img = tw.decode_final(lat)
+        assert torch.isfinite(img).all()
+        lats.append(lat[:len(b)])
+    local = torch.cat(lats) if lats else torch.zeros(0, 4, tw.h, tw.w, device=device)
+    torch.cuda.synchronize()
+    gathered = local
+    if world > 1 and args.num_seeds:                   # the result gather: the only collective of the path
+        gathered = D.gather_latents(local.contiguous(), total, rank, world)
+        assert gathered.shape[0] == total and torch.isfinite(gathered).all()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    if world > 1:
+        dt = D.max_over_ranks(dt, device)
+    n_local = len(mine)
+    calls = tw.unet_calls[n_calls:]
+    K = tw.concept_num
+    return {"images": total, "seconds": dt, "images_per_s": total / dt if dt > 0 else 0.0,
+            "rank0_seconds_per_image_loop_only": t_loop / max(1, n_local), "rank0_images": n_local,
+            "unet_calls_per_image": len(calls) // max(1, len(batches)),
+            "calls_BK1": sum(1 for c in calls if c[1] == K + 1) // max(1, len(batches)),
+            "calls_B2": sum(1 for c in calls if c[1] == 2) // max(1, len(batches)),
+            "includes": "50-step sample_loop (start + 10 resampling repeats, plain, 5 jumping look-ahead steps, fusion) + final VAE decode"
+                        + (" + RCCL all_gather of the latents" if world > 1 and args.num_seeds else "")}
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(args, parts, K=3):
-    """the oracle (fp32 torch-CPU restatement of the same UNet) on `cpu_rows` of the K+1 batch rows of one
-    fusion step; steps/s extrapolated by (K+1)/rows (rows are independent inside the UNet)."""
+    """the oracle (fp32 torch-CPU restatement of the same UNet) on the GPU box's host cores.  Measured: BASELINE.json
+    config 1 -- one B=K+1 call and one B=2 call at 512x512, combined with that config's 27 / 18 call schedule; and, kept as
+    `extrapolated_1024`, one batch row of the 1024x1024 fusion-step call scaled by K+1 (rows are independent)."""
     from oracle import unet_oracle as UO
     sd, con, te, ts, cfg = parts
     ocfg = UO.TINY if args.tiny else UO.SDXL
     t0 = time.time()
     sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
-    orc = UO.UNetOracle(ocfg, sd_cpu)        # row 0 (uncond) uses base weights only
-    rows = args.cpu_rows
-    h = w = args.res // 8
-    torch.manual_seed(0)
-    x = torch.randn(rows, 4, h, w)
-    tid = torch.tensor([[args.res, args.res, 0, 0, args.res, args.res]] * rows, dtype=torch.float32)
+    orc = UO.UNetOracle(ocfg, sd_cpu)        # base weights (the concept deltas do not change the cost)
     cores = min(os.cpu_count() or 1, args.cpu_threads)     # torch-CPU stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(cores)
     prep = time.time() - t0
-    t1 = time.time()
-    orc.forward(x, 781, te[0][:rows], te[1][:rows], tid)
-    dt = time.time() - t1
-    return dict(value=rows / ((K + 1) * dt), unit="steps/s", cores=cores, kind="port",
-                sample=f"{rows} of {K + 1} batch rows of one fusion-step UNet forward at {args.res}x{args.res} "
-                       f"(fp32 torch-CPU oracle, {dt:.1f}s; weight copy {prep:.1f}s not counted); rows are independent, "
-                       f"so steps/s = rows/((K+1)*t); fused epilogue negligible")
+
+    def call(rows, res):
+        h = w = res // 8
+        torch.manual_seed(0)
+        x = torch.randn(rows, 4, h, w)
+        tid = torch.tensor([[res, res, 0, 0, res, res]] * rows, dtype=torch.float32)
+        t1 = time.time()
+        orc.forward(x, 781, te[0][:rows], te[1][:rows], tid)
+        return time.time() - t1
+
+    small = 512 if not args.tiny else args.res
+    t4 = call(K + 1, small)
+    t2 = call(2, small)
+    traj = 27 * t4 + 18 * t2                 # BASELINE.md section 2: config 1 = 27 calls at B=4 + 18 at B=2
+    t1row = call(1, args.res)
+    return dict(value=1.0 / t4, unit="steps/s", cores=cores, kind="port",
+                sample=f"BASELINE config 1 shapes ({small}x{small}, K=3): one fusion-step UNet call at B={K + 1} ({t4:.1f}s) and one CFG-pair "
+                       f"call at B=2 ({t2:.1f}s), fp32 torch-CPU oracle, {cores} threads; value = fusion-phase steps/s at {small}^2 "
+                       f"(fused epilogue negligible); weight copy {prep:.1f}s not counted",
+                config1={"resolution": small, "t_call_B4_s": t4, "t_call_B2_s": t2, "calls": "27 @B=4 + 18 @B=2",
+                         "trajectory_s": traj, "trajectory_steps_per_s": 20.0 / traj},
+                extrapolated_1024={"steps_per_s": 1.0 / ((K + 1) * t1row), "t_one_row_s": t1row,
+                                   "how": f"1 of {K + 1} batch rows of the {args.res}x{args.res} fusion-step call; rows are independent, so steps/s = 1/((K+1)*t)"})
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+# ------------------------------------------------------------------------------------------------ dry run (CPU tests)
+def host_dry_run(args, rank, world):
+    """the N-rank control flow of this script without a GPU: rendezvous, barrier-bracketed timing, MAX over ranks, seed
+    sharding and the latent gather, over gloo.  The step is a stand-in; the line says so."""
+    import torch.distributed as dist
+    from tweediemix_amd import dist as D
+    if world > 1:
+        dist.init_process_group("gloo")
+    x = torch.full((args.seeds_per_gpu, 4, 8, 8), float(rank))
+    for _ in range(args.warmup):
+        x = x * 0.5 + 1.0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = x * 0.5 + 1.0
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = D.max_over_ranks(dt, torch.device("cpu"))
+    total = args.num_seeds or world * args.seeds_per_gpu
+    mine = D.seed_shard(list(range(total)), rank, world) if args.num_seeds else [rank * args.seeds_per_gpu + i for i in range(args.seeds_per_gpu)]
+    local = torch.stack([torch.full((4, 8, 8), float(s)) for s in mine]) if mine else torch.zeros(0, 4, 8, 8)
+    gathered = D.gather_latents(local, total, rank, world) if (world > 1 and args.num_seeds) else local
+    ok = (not args.num_seeds) or all(float(gathered[i, 0, 0, 0]) == float(i) for i in range(total))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": world * args.seeds_per_gpu * args.steps / dt, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "DRY RUN: launcher / collective control flow on CPU over gloo, stand-in step, no kernels -- not a measurement",
+                          "config": {"workload": "none (host dry run)", "seeds_total": total, "gather_ok": bool(ok)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    args = parse(argv)
+    from tweediemix_amd import launch as LA
+    if args.gpus > 1 and not LA.launched():
+        return LA.self_launch(args.gpus)
+    rank, local, world = LA.rank_env()
+    if args.host_dry_run:
+        return host_dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     if os.environ.get("TMIX_SINGLE_GPU_DIST_TEST"):     # debug only: all ranks share GPU 0 over gloo (control-flow test)
         local = 0
@@ -229,103 +405,72 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    tw, parts = build_sampler(args, device, seed=rank)       # each rank owns its own seeds (weak scaling)
-    K = tw.concept_num
+    primary = "lora" if args.kind in ("both", "lora") else "custom"
+    tw, parts = build_sampler(args, primary, device, seed=rank)       # each rank owns its own seeds (weak scaling)
+    K, S_ = tw.concept_num, args.seeds_per_gpu
     plan = tw.plan("fusion")
-    fusion_ts = [t for t in tw.scheduler.timesteps if t <= tw.t_cond_cur and t in tw._window]
-    seed_gen = torch.Generator().manual_seed(1000 + rank)
-    S = args.seeds_per_gpu
-    x = torch.randn(S, 4, tw.h, tw.w, generator=seed_gen).to(device)
-
-    def step(i, x):
-        from tweediemix_amd import lib as L
-        t = fusion_ts[i % len(fusion_ts)]
-        eps = tw._unet("fusion", x, t)
-        return tw._step(x, eps, L.STEP_FUSION, tw.alpha(t), tw.alpha(t - tw.skip))
-
-    for i in range(args.warmup):
-        x = step(i, x)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        x = step(args.warmup + i, x)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert torch.isfinite(x).all()
+    x = torch.randn(S_, 4, tw.h, tw.w, generator=torch.Generator().manual_seed(1000 + rank)).to(device)
+    dt, _x = timed_fusion_steps(tw, args, world, device, x)
     if world > 1:
         from tweediemix_amd import dist as D
         dt = D.max_over_ranks(dt, device)
-        # result gather (the only collective on this path): final latents of every rank's seeds
-        gathered = D.gather_latents(x[:1].contiguous(), world, rank, world)
-        assert gathered.shape[0] == world and torch.isfinite(gathered).all()
+    check = parity_check(tw, args, parts, primary, device)
+    prof = insitu_profile(tw) if rank == 0 else None
+    traj = None if args.no_trajectory else run_trajectories(tw, args, rank, world, device)
 
-    traj = None
-    if args.trajectory:
-        # whole sample_loop with the reference's default flags (n=50, t_cond=0.2, resampling 10, jumping 5): SURVEY 8d(ii)
-        from tweediemix_amd import masks as M
-        imgs = M.random_rectangle_masks(K, args.res, args.res, seed=7)
-        if S > 1:                       # the sampler asks once per seed, in seed order: hand out that seed's mask set
-            per_seed, turn = tw.masks.clone(), [0]
+    other = {}
+    if args.kind == "both" and world == 1:
+        alg = gemm_alg_bytes(plan)
+        flops_step = plan.flops
+        del tw, plan
+        torch.cuda.empty_cache()
+        tw2, _parts2 = build_sampler(args, "custom", device, seed=rank)
+        dt2, _ = timed_fusion_steps(tw2, args, world, device, x)
+        other["custom"] = {"workload": "BASELINE configs[1]: Custom-Diffusion K/V deltas", "value": S_ * args.steps / dt2, "unit": "steps/s",
+                           "ms_per_step": 1e3 * dt2 / (args.steps * S_), "parity_check": parity_check(tw2, args, _parts2, "custom", device)}
+        del tw2
+        torch.cuda.empty_cache()
+    else:
+        alg = gemm_alg_bytes(plan)
+        flops_step = plan.flops
 
-            def provider(x0):
-                turn[0] += 1
-                return per_seed[(turn[0] - 1) % S]
-            tw.mask_provider = provider
-        else:
-            tw.mask_provider = lambda x0: M.build_masks(imgs, tw.h, tw.w, device)
-        xT = torch.randn(S, 4, tw.h, tw.w, generator=seed_gen)
-        from tweediemix_amd import vae as V
-        tw.vae = (V.FULL, V.synthetic_state_dict(V.FULL, device=device))     # random-init decoder of the SDXL VAE shapes
-        tw.unet_calls.clear()
-        tw.run_fusion(xT.clone(), decode=True)          # builds/captures the start / plain / VAE plans too
-        torch.cuda.synchronize()
-        n_calls = len(tw.unet_calls)
-        t1 = time.perf_counter()
-        lat = tw.run_fusion(xT.clone())
-        torch.cuda.synchronize()
-        dtt = time.perf_counter() - t1
-        img = tw.decode_final(lat)
-        torch.cuda.synchronize()
-        dti = time.perf_counter() - t1
-        assert torch.isfinite(lat).all() and torch.isfinite(img).all()
-        traj = {"trajectory_steps_per_s": 50 * S / dtt, "seconds_per_image": dtt / S, "unet_calls_per_image": n_calls,
-                "images_per_s_incl_vae_decode": S / dti, "vae_decode_ms": 1e3 * (dti - dtt) / S,
-                "calls_B4": sum(1 for c in tw.unet_calls[n_calls:] if c[1] == K + 1), "calls_B2": sum(1 for c in tw.unet_calls[n_calls:] if c[1] == 2)}
     if rank == 0:
-        roof = gemm_roofline(plan)
-        g = roof["gemm"]
+        g = prof["gemm"]
         line = {
-            "metric": "denoise steps/sec @ SDXL 1024^2 K=3 concepts (fusion phase)",
-            "value": world * S * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / (args.steps * S), "higher_is_better": True,
+            "metric": METRIC, "value": world * S_ * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / (args.steps * S_), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SDXL-base UNet shapes, {args.res}x{args.res}, K=3 concepts ({args.kind} deltas), "
-                                   f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel"
+            "config": {"workload": f"SDXL-base UNet shapes, {args.res}x{args.res}, K=3 concepts ({primary} deltas"
+                                   + (", --t_stop 0.8 window" if primary == "lora" else "") + "), "
+                                   f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel, one hipGraph per step"
                                    + (" [TINY DEBUG CONFIG]" if args.tiny else ""),
-                       "seeds_per_gpu": S, "streams": args.streams, "hip_graph": not args.no_graphs, "parallelism": f"replicas x{world} (seed-sharded)"},
-            "unet_tflop_per_step": plan.flops / 1e12 / S,
-            "achieved_tflops_whole_step": plan.flops / 1e12 / (dt / args.steps),
-            "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<0> (tmix_gemm_bf16)", "achieved": g["tflops"],
-                         "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": g["alg_bytes_per_launch"], "launches_per_step": g["launches"], "avg_launch_us": g["avg_us"],
-                         "flops_per_step": g["flops"], "concurrent_replay": gemm_concurrent(plan),
-                         "other_kernels": {k: {kk: v[kk] for kk in ("launches", "total_ms", "avg_us", "tflops")}
-                                           for k, v in roof.items() if k != "gemm"}},
+                       "seeds_per_gpu": S_, "streams": args.streams, "hip_graph": not args.no_graphs,
+                       "parallelism": f"replicas x{world} (seed-sharded, no data-path collective)"},
+            "unet_tflop_per_step": flops_step / 1e12 / S_,
+            "achieved_tflops_whole_step": flops_step / 1e12 / (dt / args.steps),
+            "parity_check": check,
+            "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<..,CONV=0> (tmix_gemm_bf16)",
+                         "achieved": g["tflops"], "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,
+                         "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": alg,
+                         "how": "achieved = sum(2MNK of the step's GEMM launches) / sum(their durations), each launch timed on the device clock "
+                                "INSIDE the captured step while the graph replays (concurrent chains included, so the sum can exceed the wall time)",
+                         "launches_per_step": g["launches"], "avg_launch_us": g["avg_launch_us"], "flops_per_step": g["flops"],
+                         "graph_replay_ms": prof["replay_ms"], "instrumented_busy_ms": prof["instrumented_busy_ms"],
+                         "classes": {k: {kk: v[kk] for kk in ("launches", "sum_launch_ms", "busy_ms", "avg_launch_us", "tflops")}
+                                     for k, v in prof.items() if isinstance(v, dict)}},
         }
         if traj is not None:
+            line["images_per_s"] = traj["images_per_s"]
             line["trajectory"] = traj
+        if other:
+            line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, parts)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -17,6 +17,11 @@ the loop through the HF hub (checkpoint download) takes local paths here:
   --mask_paths           '+'-separated 8-bit masks for the foreground concepts (what run_expand.py would write
                          as '<concept>.jpg'); --random_masks draws seeded rectangles instead
   --synthetic            random-init weights / embeddings of the SDXL shapes (no checkpoints exist offline)
+  --num_seeds N          N trajectories, seeds seed..seed+N-1 (trajectory i is exactly what `--seed seed+i` alone produces: its
+                         x_T comes from its own generator), co-batched --seeds_per_batch at a time
+  --gpus G               shard those seeds round-robin over G GPUs of this node: the script starts one process per GPU itself
+                         (or runs under torch.distributed.run), every rank samples its seeds, the final latents are gathered
+                         over RCCL and rank 0 writes the files (BASELINE config 4; the reference is single-GPU, sample_catdog.sh:3)
 
 Output: {output_path_all}/{prompt_orig}_{seed}.latent.pt, plus the .png when VAE weights are given.
 """
@@ -35,13 +40,14 @@ LORA = False
 
 def build_parser():
     p = argparse.ArgumentParser()
-    # --- the reference's flags, same names / defaults (fusion_sampling.py:534-585)
+    # --- the reference's flags, same names / defaults (fusion_sampling.py:534-585); output_path / output_path_all have no
+    # default there (None crashes at os.makedirs), here they fall back to ./results{,_all}
     p.add_argument('--seed', type=int, default=182)
-    p.add_argument('--device', type=str, default='cuda')
+    p.add_argument('--device', type=str, default='cuda:0')
     p.add_argument('--output_path', type=str, default='results')
     p.add_argument('--output_path_all', type=str, default='results_all')
-    p.add_argument('--negative_prompt', type=str, default='')
-    p.add_argument('--sd_version', type=str, default='xl', choices=['1.4', '1.5', '2.0', '2.1', 'xl'])
+    p.add_argument('--negative_prompt', type=str, default='blurry, ugly, black, low res, unrealistic, blurry face')
+    p.add_argument('--sd_version', type=str, default='2.1', choices=['1.4', '1.5', '2.0', '2.1', 'xl'])
     p.add_argument('--t_cond', type=float, default=0.4)
     p.add_argument('--guidance_scale', type=float, default=9.0)
     p.add_argument('--n_timesteps', type=int, default=50)
@@ -68,7 +74,11 @@ def build_parser():
     p.add_argument('--text_embeds_path', type=str, default='')
     p.add_argument('--mask_paths', type=str, default='')
     p.add_argument('--random_masks', action='store_true')
-    p.add_argument('--num_seeds', type=int, default=1, help='co-batched trajectories (seeds seed..seed+n-1)')
+    p.add_argument('--num_seeds', type=int, default=1, help='trajectories to sample: seeds seed..seed+n-1')
+    p.add_argument('--seeds_per_batch', type=int, default=0, help='seeds co-batched into every UNet launch (0: all of this rank\'s seeds, at most 4)')
+    p.add_argument('--gpus', type=int, default=1, help='shard the seeds over this many GPUs (one process per GPU, started by this script)')
+    p.add_argument('--no_strict_reference', action='store_true',
+                   help='route the concept weights for any concept count (the reference hooks only route when the UNet batch is 4, i.e. 3 concepts)')
     p.add_argument('--streams', type=int, default=2)
     p.add_argument('--no_graphs', action='store_true')
     p.add_argument('--tiny', action='store_true', help='tiny UNet config (smoke tests)')
@@ -101,11 +111,27 @@ def save_png(img, path):
     Image.fromarray(a).save(path)
 
 
+def noise_for_seed(seed, h, w):
+    """x_T of one trajectory, drawn on the CPU like fusion_sampling.py:488 after seed_everything(seed) (utils_custom.py:10-14
+    seeds torch's global generator; a fresh generator with the same seed yields the same first draw)."""
+    return torch.randn(1, 4, h, w, generator=torch.Generator().manual_seed(int(seed)))
+
+
 def main(argv=None):
     opt = build_parser().parse_args(argv)
-    from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
+    from tweediemix_amd import dist as D, launch as LA, masks as M, sampler as S, unet as U, weights as Wt
+    if opt.gpus > 1 and not LA.launched():
+        return LA.self_launch(opt.gpus)
+    rank, local, world = LA.rank_env()
+    if world > 1:
+        import torch.distributed as dist
+        single = bool(os.environ.get('TMIX_SINGLE_GPU_DIST_TEST'))      # tests: all ranks on GPU 0, gloo
+        opt.device = 'cuda:0' if single else f'cuda:{local}'
+        torch.cuda.set_device(torch.device(opt.device))
+        dist.init_process_group('gloo' if single else 'nccl')
+    say = print if rank == 0 else (lambda *a, **k: None)
     if opt.sd_version != 'xl':
-        print(f"note: --sd_version {opt.sd_version}: like the reference (fusion_sampling.py:119) only the SDXL pipeline exists")
+        say(f"note: --sd_version {opt.sd_version}: like the reference (fusion_sampling.py:119) only the SDXL pipeline exists")
     concepts = [c for c in opt.concepts.split('+') if c] or ['a', 'b', 'background']
     K = len(concepts)                                    # concept_num, background last (fusion_sampling.py:143-148)
     cfg = U.TINY if opt.tiny else U.SDXL
@@ -145,7 +171,7 @@ def main(argv=None):
     else:   # the reference's file contract (:453-466): the side-car writes '<seg_concept>.jpg' under output_path
         fg = [os.path.join(opt.output_path, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
         sidecar = True
-    vae = None
+    vae, vae_scaling = None, None
     vae_dir = opt.vae_path or (opt.sd_path and os.path.isdir(os.path.join(opt.sd_path, 'vae')) and os.path.join(opt.sd_path, 'vae'))
     if vae_dir:
         from tweediemix_amd import vae as V
@@ -156,34 +182,62 @@ def main(argv=None):
             vcfg = dict(block_out_channels=tuple(j['block_out_channels']), layers_per_block=j.get('layers_per_block', 2),
                         latent_channels=j.get('latent_channels', 4), out_channels=j.get('out_channels', 3),
                         groups=j.get('norm_num_groups', 32))
+            vae_scaling = j.get('scaling_factor')
         vae = (vcfg, load_state_dict(find_weights(vae_dir, 'diffusion_pytorch_model')))
     elif opt.synthetic and opt.tiny:
         from tweediemix_amd import vae as V
         vae = (V.TINY, V.synthetic_state_dict(V.TINY))
+    seeds = D.seed_shard([opt.seed + i for i in range(opt.num_seeds)], rank, world)
+    per = opt.seeds_per_batch or min(max(len(seeds), 1), 4)
+    strict = not opt.no_strict_reference
+    if strict and K + 1 != 4 and kind in ('custom', 'lora'):
+        say(f"note: {K} concepts -> UNet batch {K + 1}: the reference's attention hooks only route concept weights when the batch is 4 "
+            f"(utils_custom.py:62, utils_lora.py:63), so like the reference this run uses the BASE weights for every row; "
+            f"--no_strict_reference routes them")
     tw = S.Tweediemix(opt, W, te, ts, lambda x0: M.build_masks(fg, h, w, opt.device), concept_num=K, lora=LORA,
-                      use_graphs=not opt.no_graphs, n_seeds=opt.num_seeds, n_streams=opt.streams, vae=vae)
+                      strict_reference=strict, use_graphs=not opt.no_graphs, n_seeds=per, n_streams=opt.streams, vae=vae)
+    if vae_scaling:                                       # fusion_sampling.py:518 divides by vae.config.scaling_factor
+        tw.vae_scaling_factor = float(vae_scaling)
     if sidecar and vae is not None:
         # with a VAE the whole contract runs like the reference: decode the Tweedie preview to {output_path}/tweedie.jpg,
         # call `CUDA_VISIBLE_DEVICES={seg_gpu} python text_segment/run_expand.py ...` (TMIX_SEG_CMD overrides the command),
         # read the masks back; without one the mask files must already be there
         tw.mask_provider = M.SidecarMaskProvider(tw, opt.output_path, opt.seg_concepts, seg_gpu=opt.seg_gpu,
                                                  cmd_template=os.environ.get('TMIX_SEG_CMD'))
-    x = torch.randn(opt.num_seeds, 4, h, w)             # CPU draw after seed_everything, like :488
-    lat = tw.run_fusion(x)
-    os.makedirs(opt.output_path_all, exist_ok=True)
-    prompt_orig = opt.prompt_orig.split('+')[0] or 'sample'
-    for i in range(opt.num_seeds):
-        out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.latent.pt'
-        torch.save(lat[i:i + 1].cpu(), out)
-        print('saved', out)
-    if vae is not None:                                   # fusion_sampling.py:496-528
-        img = tw.decode_final(lat)
+    lats, imgs = [], []
+    for b0 in range(0, len(seeds), per):
+        batch = seeds[b0:b0 + per]
+        ids = (batch + batch * per)[:per]                # a ragged last batch is padded with repeats and trimmed below
+        lat_b = tw.run_fusion(torch.cat([noise_for_seed(sd_, h, w) for sd_ in ids]))
+        lats.append(lat_b[:len(batch)])
+        if vae is not None:                               # fusion_sampling.py:496-528
+            imgs.append(tw.decode_final(lat_b)[:len(batch)])
+    dev = torch.device(opt.device)
+    lat = torch.cat(lats) if lats else torch.zeros(0, 4, h, w, device=dev)
+    img = torch.cat(imgs) if imgs else None
+    if world > 1:                                         # the result gather: the only collective of this path
+        import torch.distributed as dist
+        lat = D.gather_latents(lat.contiguous(), opt.num_seeds, rank, world)
+        if vae is not None:
+            img = D.gather_latents(img.contiguous() if img is not None else torch.zeros(0, 3, opt.resolution_h, opt.resolution_w, device=dev),
+                                   opt.num_seeds, rank, world)
+    if rank == 0:
+        os.makedirs(opt.output_path_all, exist_ok=True)
+        prompt_orig = opt.prompt_orig.split('+')[0] or 'sample'
         for i in range(opt.num_seeds):
-            out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.png'
-            save_png(img[i], out)
+            out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.latent.pt'
+            torch.save(lat[i:i + 1].cpu(), out)
             print('saved', out)
+            if vae is not None:
+                out = f'{opt.output_path_all}/{prompt_orig}_{opt.seed + i}.png'
+                save_png(img[i], out)
+                print('saved', out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return lat
 
 
 if __name__ == '__main__':
-    main()
+    rc = main()
+    sys.exit(rc if isinstance(rc, int) else 0)

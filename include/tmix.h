@@ -35,6 +35,16 @@ const char* tmix_last_error_string(void);
 /* 0 if the current device is gfx950, TMIX_EARCH otherwise, >0 on HIP errors. */
 int tmix_check_device(void);
 
+/* In-situ launch timing (measurement only; no reference counterpart).  Between tmix_prof_begin and tmix_prof_end every
+ * tmix_gemm_bf16 / tmix_conv3x3_nhwc / tmix_attn_fwd / tmix_groupnorm_nhwc launch issued by THIS host thread -- also while
+ * it is being captured into a hipGraph -- takes the next 8-word slot of `slots` (device memory, capacity slots) and its
+ * workgroups record into it, in ticks of the 100 MHz realtime clock: {min start, max end, sum(first operands landed -
+ * start), sum(main loop done - start), sum(workgroup end - start), workgroups, -, -}.  The caller initialises every slot
+ * to {UINT64_MAX, 0, 0, 0, 0, 0, 0, 0} before each measured run / replay.  tmix_prof_end returns the number of slots
+ * handed out.  Launches issued outside such a bracket carry no instrumentation. */
+int tmix_prof_begin(uint64_t* slots, int capacity);
+int tmix_prof_end(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused CFG + Tweedie x0 + mask blend + DDIM update.
  * Replaces fusion_generation/fusion_sampling.py:376-385,430,471-472 (fusion branch),
@@ -57,6 +67,18 @@ int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_dtype, cons
                             float* out_x, float* out_x0, int K, int channels, int64_t hw, int mode,
                             float g, float sa, float s1, float sa_next, float s1_next, int is_last,
                             void* stream);
+/* The same step with its coefficients in DEVICE memory, for hipGraph capture of a whole denoising step (the loop body of
+ * fusion_sampling.py:490-494 becomes one graph replay per timestep): params = fp32 {t, sa, s1, sa_next, s1_next,
+ * is_last (0/1), g, -}.  `seeds` co-batched trajectories run in one launch: x / out_x / out_x0 are [seeds][n], eps is
+ * [seeds][rows][n] (rows = the UNet batch rows per seed), masks [seeds][K][hw] with mask_seed_stride = K*hw (0: one mask
+ * set shared by all seeds).  x may alias out_x (in-place update of the latent state).  Bit-identical to the scalar form. */
+int tmix_fused_tweedie_step_dev(const float* x, const void* eps, int eps_dtype, const float* masks,
+                                int64_t mask_seed_stride, float* out_x, float* out_x0, int K, int channels,
+                                int64_t hw, int mode, int rows, int seeds, const float* params, void* stream);
+/* Head of the captured step (fusion_sampling.py:324-327, `latent_model_input = torch.cat([x] * rows)`, and the timestep
+ * argument of the UNet call :340): latent[(s*rows + r)][n] = x[s][n] for every row r, t_dev[s*rows + r] = params[0]. */
+int tmix_step_prologue(const float* x, float* latent, float* t_dev, const float* params, int seeds, int rows,
+                       int64_t n, void* stream);
 
 /* Video sampler (I2VGen-XL loop, BASELINE config #5; replaces video_gen/pipeline_i2vgen_xl.py:699-719):
  *   x [n], v [2n] (uncond rows first), out [n], all of `dtype` (TMIX_F32 / TMIX_F16 / TMIX_BF16); sa = sqrt(alpha(t)) etc. with
@@ -89,7 +111,9 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_64x160_W5 = 13 /* five waves of 64x32, 4-deep ring: 2048 x 1280 is exactly 256 tiles (one per CU) */,
        TMIX_TILE_256x320_S2 = 14 /* eight waves of 64x160: 2048 x 10240 (GEGLU up-projection) is exactly 256 tiles */,
        TMIX_TILE_32x160_W5 = 15 /* five waves of 32x32: 1024 x 1280 (one batch row per chain) is 256 tiles */,
-       TMIX_TILE_COUNT = 15 };
+       TMIX_TILE_256x256_PH = 16 /* eight waves, K slices of 32 through a four-slot ring, the second wave of each SIMD one barrier behind the first */,
+       TMIX_TILE_256x128_PH = 17,
+       TMIX_TILE_COUNT = 17 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

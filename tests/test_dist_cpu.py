@@ -54,3 +54,50 @@ def test_seed_shard_round_robin():
     from tweediemix_amd import dist as D
     assert D.seed_shard(list(range(10)), 1, 4) == [1, 5, 9]
     assert sum(len(D.seed_shard(list(range(64)), r, 8)) for r in range(8)) == 64
+
+
+def _json_lines(out):
+    import json
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("num_seeds", [0, 5])
+def test_bench_gpus2_launches_its_own_ranks(num_seeds):
+    """`python bench.py --gpus 2` with NO outer launcher starts two ranks itself (tweediemix_amd/launch.py), rendezvous on
+    127.0.0.1, barrier-bracketed timing, MAX over ranks, seed sharding + latent gather, ONE line from rank 0 with n_gpus == 2.
+    CPU stand-in step (--host-dry-run): the control flow is the GPU run's, the kernels are not involved."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--host-dry-run", "--steps", "3", "--warmup", "1"]
+    if num_seeds:
+        cmd += ["--num-seeds", str(num_seeds)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["gather_ok"] is True
+    assert d["config"]["seeds_total"] == (num_seeds or 2) and "DRY RUN" in d["data"]
+
+
+def test_self_launch_propagates_failure(tmp_path):
+    """a rank that dies takes the job down with a non-zero exit code (no hung rendezvous)."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "job.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, time
+        sys.path.insert(0, {root!r})
+        from tweediemix_amd import launch as LA
+        if not LA.launched():
+            sys.exit(LA.self_launch(2))
+        rank, local, world = LA.rank_env()
+        assert world == 2 and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        if rank == 1:
+            sys.exit(7)
+        time.sleep(30)
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script)], timeout=25, env=env)
+    assert r.returncode == 7

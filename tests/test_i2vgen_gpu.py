@@ -68,6 +68,36 @@ def test_full_architecture_small_frames_match_oracle():
     assert r < 2e-2, r
 
 
+def test_full_architecture_at_768x448_16_frames_two_chains():
+    """BASELINE config 5 at the size its number is quoted on: 2 clips (the CFG pair) x 16 frames of 56 x 96 latents (768 x 448),
+    the real 1.42 B-parameter configuration, the two clips as two launch chains (I2VPlanGroup) replayed as a hipGraph --
+    against the fp32 restatement evaluated on the same GPU."""
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I
+    B, Fr, H, W, Lk = 2, 16, 56, 96, 77
+    sd, il, emb, ehs, fps, sample = _setup(IO.FULL, I.FULL, B, Fr, H, W, Lk)
+    Wt = I.I2VWeights(I.FULL, sd)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    grp = I.I2VPlanGroup(Wt, B, Fr, H, W, fe, ctx, ilf)
+    out = grp(sample, 501).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        grp.run()
+    grp.eps.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    out2 = grp.eps.view(B, Fr, 4, H, W).permute(0, 2, 1, 3, 4).clone()
+    dev = lambda t: t.cuda()
+    sd_g = {k: v.cuda() for k, v in sd.items()}
+    fe_o, ctx_o, ilf_o = IO.conditioning(sd_g, IO.FULL, dev(fps), dev(il), dev(emb), dev(ehs))
+    want = IO.forward(sd_g, IO.FULL, dev(sample), 501, fe_o, ctx_o, ilf_o)
+    torch.cuda.synchronize()
+    r, r2 = rel(out, want), rel(out2, want)
+    print("I2VGen-XL 768x448x16 two chains: rel-L2 eager", r, "graph replay", r2)
+    assert r < 2e-2 and r2 < 2e-2, (r, r2)
+
+
 def test_video_loop_on_the_plan():
     """tweediemix_amd.video.sample_loop driving the plan: CFG batch of 2 clips, v-prediction update, injection hooks off."""
     from oracle import i2vgen_oracle as IO

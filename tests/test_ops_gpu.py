@@ -75,6 +75,108 @@ def test_tweedie_step_bit_exact(ops, dt, mode, K, h, w, last):
         assert np.array_equal(x0.cpu().numpy(), ref0)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("mode", ["fusion", "plain", "resample"])
+@pytest.mark.parametrize("seeds,per_seed_masks,last", [(1, False, False), (3, True, False), (2, False, True)])
+def test_tweedie_step_device_params_multi_seed_in_place(ops, dt, mode, seeds, per_seed_masks, last):
+    """tmix_fused_tweedie_step_dev (coefficients from device memory, all co-batched seeds in one launch, latent updated IN
+    PLACE -- the form the captured whole-step graph uses) against the numpy oracle bit for bit, seed by seed."""
+    from oracle import tweedie_oracle as TO
+    from tweediemix_amd import lib as L, ops as O
+    lib = L.load()
+    K, h, w = 3, 12, 20
+    rows = 2 if mode == "plain" else K + 1
+    rng = np.random.RandomState(7 + seeds)
+    x = rng.randn(seeds, 4, h, w).astype(np.float32)
+    eps = rng.randn(seeds * rows, 4, h, w).astype(np.float32)
+    masks = (rng.rand(seeds if per_seed_masks else 1, K, 1, h, w) > 0.5).astype(np.float32)
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    eps_t = torch.from_numpy(eps).to(tdt).cuda()
+    eps_r = eps_t.float().cpu().numpy()
+    at, an, g = np.float32(0.4111), np.float32(0.5222), 0.8
+    lowp = np.float16 if dt == "f16" else None
+    m = {"fusion": L.STEP_FUSION, "plain": L.STEP_PLAIN, "resample": L.STEP_RESAMPLE}[mode]
+    if mode == "resample":
+        last = False
+    sa, s1, san, s1n = O.step_coeffs(at, an)
+    prm = torch.tensor([781.0, sa, s1, san, s1n, 1.0 if last else 0.0, g, 0.0], dtype=torch.float32).cuda()
+    xt = torch.from_numpy(x).cuda()
+    x0 = torch.full_like(xt, float("nan"))
+    mt = torch.from_numpy(masks).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.tmix_fused_tweedie_step_dev(xt.data_ptr(), eps_t.data_ptr(), {"f32": L.F32, "f16": L.F16, "bf16": L.BF16}[dt],
+                                         mt.data_ptr(), K * h * w if per_seed_masks else 0, xt.data_ptr(), x0.data_ptr(), K, 4, h * w, m,
+                                         rows, seeds, prm.data_ptr(), st)
+    L.check(rc, "tmix_fused_tweedie_step_dev")
+    torch.cuda.synchronize()
+    for sd in range(seeds):
+        e = eps_r[sd * rows:(sd + 1) * rows]
+        mk = masks[sd if per_seed_masks else 0]
+        if mode == "fusion":
+            ref, ref0 = TO.fused_fusion_step(x[sd:sd + 1], e, mk, g, at, an, last, lowp)
+        elif mode == "plain":
+            ref, ref0 = TO.fused_plain_step(x[sd:sd + 1], e, g, at, an, last, lowp)
+        else:
+            ref, ref0 = TO.fused_resample_down(x[sd:sd + 1], e, K, g, at, an, lowp), None
+        assert np.array_equal(xt[sd:sd + 1].cpu().numpy(), ref), (sd, np.abs(xt[sd:sd + 1].cpu().numpy() - ref).max())
+        if ref0 is not None:
+            assert np.array_equal(x0[sd:sd + 1].cpu().numpy(), ref0)
+
+
+def test_step_prologue_broadcasts_latent_and_timestep(ops):
+    from tweediemix_amd import lib as L
+    lib = L.load()
+    seeds, rows, h, w = 3, 4, 16, 24
+    x = torch.randn(seeds, 4, h, w, device="cuda")
+    lat = torch.zeros(seeds * rows, 4, h, w, device="cuda")
+    t_dev = torch.zeros(seeds * rows, device="cuda")
+    prm = torch.tensor([421.0, 0, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device="cuda")
+    L.check(lib.tmix_step_prologue(x.data_ptr(), lat.data_ptr(), t_dev.data_ptr(), prm.data_ptr(), seeds, rows, 4 * h * w,
+                                   torch.cuda.current_stream().cuda_stream), "tmix_step_prologue")
+    torch.cuda.synchronize()
+    assert torch.equal(lat.view(seeds, rows, 4, h, w), x.unsqueeze(1).expand(-1, rows, -1, -1, -1))
+    assert torch.equal(t_dev, torch.full_like(t_dev, 421.0))
+
+
+def test_prof_hook_times_launches_also_inside_a_graph(ops):
+    """tmix_prof_begin / tmix_prof_end: every instrumented launch takes one slot, the slots are filled when the work runs
+    (eagerly or as a hipGraph replay), and a launch outside the bracket is untouched."""
+    from tweediemix_amd import lib as L
+    lib = L.load()
+    a, w_ = rnd(1024, 1280, seed=1), rnd(1280, 1280, seed=2, scale=0.03)
+    x = rnd(2, 32 * 32, 320, seed=3)
+    gam, bet = torch.ones(320, device="cuda"), torch.zeros(320, device="cuda")
+    slots = torch.zeros(4, 8, dtype=torch.int64, device="cuda")
+    slots[:, 0] = -1
+    init = slots.clone()
+
+    def work():
+        ops.gemm(a, w_)
+        ops.groupnorm(x, gam, bet, 32, 1e-5, silu=True)
+
+    work()
+    torch.cuda.synchronize()
+    L.check(lib.tmix_prof_begin(slots.data_ptr(), 4), "tmix_prof_begin")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        work()
+    assert lib.tmix_prof_end() == 2
+    assert torch.equal(slots, init)                      # capture does not execute
+    work()                                               # outside the bracket: no slot, nothing written
+    torch.cuda.synchronize()
+    assert torch.equal(slots, init)
+    for _ in range(2):
+        slots.copy_(init)
+        g.replay()
+        torch.cuda.synchronize()
+        s = slots.cpu().numpy().astype("uint64")
+        for k in range(2):
+            dur_us = (int(s[k, 1]) - int(s[k, 0])) * 0.01
+            assert 0.5 < dur_us < 5000.0 and s[k, 5] >= 1, (k, s[k])
+        assert int(s[1, 0]) >= int(s[0, 0])              # the norm starts after the GEMM started (same stream)
+        assert (s[2:] == init.cpu().numpy().astype("uint64")[2:]).all()
+
+
 def test_tweedie_step_rejects_bad_args(ops):
     from tweediemix_amd import lib as L
     x = torch.zeros(1, 4, 8, 8, device="cuda")

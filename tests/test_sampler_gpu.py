@@ -348,8 +348,13 @@ def test_bench_line_contract(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "parity_check", "images_per_s", "trajectory", "other_configs"):
         assert k in d, k
+    assert d["parity_check"]["rel_l2"] < d["parity_check"]["tol"] and d["images_per_s"] > 0
+    assert d["other_configs"]["custom"]["value"] > 0 and "lora" in d["config"]["workload"]
+    cls = d["roofline"]["classes"]
+    assert set(cls) >= {"gemm", "conv", "attn", "norm"} and all(c["sum_launch_ms"] > 0 and c["busy_ms"] <= c["sum_launch_ms"] + 1e-6 for c in cls.values())
+    assert d["roofline"]["instrumented_busy_ms"] <= d["roofline"]["graph_replay_ms"] * 1.05
     assert d["steps"] == 2 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
     rf, cb = d["roofline"], d["cpu_baseline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
@@ -376,3 +381,55 @@ def test_bench_two_ranks_control_flow(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     # whole-job aggregate: both ranks' seeds over the slowest rank's time
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-3
+
+
+def test_bench_gpus2_self_launch_sharded_seeds(tmp_path):
+    """`python bench.py --gpus 2 --num-seeds 3` with NO outer launcher (the way the driver invokes it): the script starts its
+    own two ranks, shards the seeds, gathers the latents, reports n_gpus == 2 and whole-job images/s.  One GPU here, so the
+    ranks share it and rendezvous over gloo (TMIX_SINGLE_GPU_DIST_TEST)."""
+    need_gpu()
+    import json, subprocess, sys
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    env = {k: v for k, v in _os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMIX_SINGLE_GPU_DIST_TEST"] = "1"
+    r = subprocess.run([sys.executable, _os.path.join(root, "bench.py"), "--gpus", "2", "--tiny", "--res", "256", "--steps", "2", "--warmup", "1",
+                        "--num-seeds", "3", "--kind", "custom"], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["trajectory"]["images"] == 3 and d["images_per_s"] > 0
+    assert "all_gather" in d["trajectory"]["includes"]
+
+
+def test_cli_sharded_seeds_equal_single_process_runs(tmp_path):
+    """BASELINE config 4 as a command: `fusion_sampling.py --gpus 2 --num_seeds 5` (two ranks started by the script, seeds
+    sharded round-robin, latents gathered, rank 0 writes the files) produces for every seed s exactly the file a
+    single-process `--seed s` run writes -- bit for bit (same launch shapes, deterministic kernels)."""
+    need_gpu()
+    import importlib.util, subprocess, sys
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    common = ["--synthetic", "--tiny", "--concepts", "a+b+bg", "--prompt_orig", "p", "--guidance_scale", "0.8", "--n_timesteps", "10",
+              "--t_cond", "0.2", "--resampling_steps", "1", "--jumping_steps", "1", "--resolution_h", "128", "--resolution_w", "128",
+              "--output_path", str(tmp_path)]
+    env = {k: v for k, v in _os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMIX_SINGLE_GPU_DIST_TEST"] = "1"
+    r = subprocess.run([sys.executable, _os.path.join(root, "fusion_generation", "fusion_sampling.py"), "--gpus", "2", "--num_seeds", "5",
+                        "--seeds_per_batch", "1", "--seed", "40", "--output_path_all", str(tmp_path / "sharded")] + common,
+                       capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    spec = importlib.util.spec_from_file_location("fs_cli3", _os.path.join(root, "fusion_generation", "fusion_sampling.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
+    for sd in (40, 43, 44):
+        fs.main(["--seed", str(sd), "--output_path_all", str(tmp_path / "single")] + common)
+        a = torch.load(tmp_path / "sharded" / f"p_{sd}.latent.pt")
+        b = torch.load(tmp_path / "single" / f"p_{sd}.latent.pt")
+        assert a.shape == (1, 4, 16, 16) and torch.equal(a, b), sd
+    # co-batched seeds reproduce the single runs to rounding (LayerNorm partial sums follow the tiling, which follows the batch)
+    fs.main(["--seed", "40", "--num_seeds", "2", "--output_path_all", str(tmp_path / "co")] + common)
+    for sd in (40, 41):
+        a = torch.load(tmp_path / "co" / f"p_{sd}.latent.pt")
+        b = torch.load(tmp_path / "sharded" / f"p_{sd}.latent.pt")
+        assert float((a - b).norm() / b.norm()) < 2e-2, sd

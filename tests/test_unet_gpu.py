@@ -182,3 +182,64 @@ def test_full_size_sdxl_unet_vs_fp32_oracle_on_gpu():
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
     print(f"SDXL full-size 512^2 B=4: rel_l2={r:.4g} max_rel={m:.4g}")
     assert r <= 2e-2 and m <= 5e-2, (r, m)
+
+
+# ------------------------------------------------------------------------------------------------ headline sizes
+@pytest.fixture(scope="module")
+def sdxl_weights():
+    """the real SDXL-base parameter shapes (2.57 B), synthetic values, built once for the headline-size tests."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tweediemix_amd import unet as U, weights as Wt
+    return Wt.synthetic_state_dict(U.SDXL, seed=1234, device="cuda", dtype=torch.float32)
+
+
+def _oracle_concepts(kind, con):
+    from oracle import unet_oracle as UO
+    if kind == "custom":
+        return UO.Concepts("custom", kv={tb: [(c[f"{tb}.attn2.to_k.weight"], c[f"{tb}.attn2.to_v.weight"]) for c in con]
+                                         for tb in UO.attention_prefixes(UO.SDXL)})
+    lo = {}
+    for tb in UO.attention_prefixes(UO.SDXL):
+        for a in ("attn1", "attn2"):
+            lo[f"{tb}.{a}"] = [{nm: (c[f"{tb}.{a}.processor.to_{nm}_lora.down.weight"], c[f"{tb}.{a}.processor.to_{nm}_lora.up.weight"])
+                                for nm in ("q", "k", "v", "out")} for c in con]
+    return UO.Concepts("lora", lora=lo)
+
+
+@pytest.mark.parametrize("kind,hw", [("custom", 128), ("lora", 128), ("lora", 64)])
+def test_headline_size_plan_group_graph_vs_fp32_oracle(sdxl_weights, kind, hw):
+    """what bench.py times: SDXL shapes at latent 128x128 (1024x1024: S = 16384 / 4096 / 1024 tokens, 65,536-row convolutions),
+    B = K+1 = 4 concept-routed rows split into TWO launch chains on two streams (PlanGroup, the shipped `shared|` tile table),
+    captured into a hipGraph and replayed -- against the fp32 torch oracle on the same GPU.  `lora`: per-row merged weight sets
+    (strideW != 0) at the full 1280 width.  Tolerance as everywhere: rel L2 <= 2e-2, max-abs <= 5e-2 * max|ref|."""
+    from oracle import unet_oracle as UO
+    from tweediemix_amd import unet as U, weights as Wt
+    cfg, sd = U.SDXL, sdxl_weights
+    con = Wt.synthetic_concepts(cfg, kind, 3, device="cuda")
+    g = torch.Generator().manual_seed(5)
+    B, res = 4, hw * 8
+    ehs = torch.randn(B, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
+    tid = torch.tensor([[float(res), res, 0, 0, res, res]] * B)
+    x = torch.randn(1, 4, hw, hw, generator=g).repeat(B, 1, 1, 1).cuda()
+    W = U.UNetWeights(cfg, sd, "cuda", (kind, con))
+    grp = U.PlanGroup(W, hw, hw, ehs, [0, 1, 2, 3], pooled, tid, True, 2)
+    assert all(p.routed == (kind == "lora") for p in grp.plans)
+    grp.latent.copy_(x)
+    grp.t_dev.fill_(601.0)
+    grp.run()                                            # warm-up outside capture
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        grp.run()
+    grp.eps.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    eps = grp.eps.clone()
+    ref = UO.UNetOracle(UO.SDXL, sd, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    torch.cuda.synchronize()
+    r = rel_l2(eps, ref)
+    m = (eps - ref).abs().max().item() / ref.abs().max().item()
+    print(f"SDXL {kind} {res}^2 B=4, two chains, graph replay: rel_l2={r:.4g} max_rel={m:.4g}")
+    assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)

@@ -1,0 +1,6 @@
+set -x
+mkdir -p gpurun_out
+L=tools/gemm_lab/lab
+timeout 300 $L check 512,512,256,1,b 1024,1280,1280,1,br 300,260,128,1,b cfgs=2,16,17 reps=5 nocold > gpurun_out/lab1_check.txt 2>&1
+timeout 600 $L 4096,10240,1280,1,g 4096,3840,1280,1,b 4096,1280,1280,1,br 4096,1280,5120,1,br 2048,1280,1280,1,br 2048,10240,1280,1,g 16384,5120,640,1,g 16384,640,640,1,br 8192,8192,8192 cfgs=1,2,4,7,9,11,14,16,17 reps=20 > gpurun_out/lab1_time.txt 2>&1
+tail -5 gpurun_out/lab1_check.txt; tail -30 gpurun_out/lab1_time.txt

@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 for kind in ("custom", "lora"):
     for streams, seeds in ((1, 1), (2, 1), (2, 2)):
         args = argparse.Namespace(kind=kind, res=1024, tiny=False, no_graphs=True, streams=streams, seeds_per_gpu=seeds)
-        tw, _ = bench.build_sampler(args, dev, seed=7)
+        tw, _ = bench.build_sampler(args, kind, dev, seed=7)
         for name in ("fusion", "fusion_base", "plain", "start"):          # every phase's plan (B = K+1, K+1, 2, K+1 rows)
             pl = tw.plan(name)
             if name in ("fusion", "plain") and hasattr(pl, "refine") and seeds == 1:   # chains that share the chip: re-rank under two-chain load

@@ -11,7 +11,7 @@ out = sys.argv[1] if len(sys.argv) > 1 else U._TUNE_FILE
 dev = torch.device("cuda:0")
 for kind, seeds in (("custom", 2), ("custom", 4), ("lora", 2)):
     args = argparse.Namespace(kind=kind, res=1024, tiny=False, no_graphs=True, streams=2, seeds_per_gpu=seeds)
-    tw, _ = bench.build_sampler(args, dev, seed=7)
+    tw, _ = bench.build_sampler(args, kind, dev, seed=7)
     pl = tw.plan("fusion")
     print(kind, seeds, "refined group step:", pl.refine(verbose=True, top=24), "ms", flush=True)
     tw.plans.clear()

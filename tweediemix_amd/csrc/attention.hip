@@ -37,6 +37,7 @@ struct AttnParams {
     bf16_t* O; int64_t ldo, strideO;
     int H, Sq, Skv, nq;
     float scale_log2e;
+    unsigned long long* prof;          // in-situ timing slot (common.h) or NULL
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
@@ -75,6 +76,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
+    const bool prof_on = p.prof != nullptr && tid == 0;
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
+    if (prof_on) pt0 = prof_enter(p.prof);
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = bid / p.nq, qt = bid - bh * p.nq;
@@ -244,6 +248,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     if (nt >= NS - 1) wait_vmcnt<(NS - 2) * LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (prof_on) pt1 = prof_now();
     int cur = 0, nxt = NS - 1;
     for (int t = 0; t < nt; ++t) {
         const bool more = t + NS - 1 < nt;
@@ -258,6 +263,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
 
+    if (prof_on) pt2 = prof_now();
     // ---- epilogue: O[q][h*64 + df*16 + fg*4 + r] = o / l
     bf16_t* Ob = p.O + (int64_t)b * p.strideO + h * 64;
 #pragma unroll
@@ -273,6 +279,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
             *(uint2*)(Ob + (int64_t)q * p.ldo + df * 16 + fg * 4) = v;
         }
     }
+    if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
 }
 
 }  // namespace
@@ -300,6 +307,7 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     p.O = (bf16_t*)O; p.ldo = ldo; p.strideO = strideO;
     p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.prof = tmix_prof_take();
     const int64_t nwg = (int64_t)p.nq * B * H;
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
     attn_fwd_kernel<<<dim3((unsigned)nwg), 256, SMEM, (hipStream_t)stream>>>(p);

@@ -11,6 +11,20 @@ void tmix_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local TmixProf g_prof = {nullptr, 0, 0};
+TmixProf& tmix_prof_state() { return g_prof; }
+
+extern "C" int tmix_prof_begin(uint64_t* slots, int capacity) {
+    if (!slots || capacity < 1 || (((uintptr_t)slots) & 7)) TMIX_FAIL(TMIX_EINVAL, "prof_begin: need an 8-byte aligned device buffer of capacity >= 1 slots");
+    g_prof.buf = (unsigned long long*)slots; g_prof.cap = capacity; g_prof.next = 0;
+    return TMIX_OK;
+}
+extern "C" int tmix_prof_end(void) {
+    const int used = g_prof.next;
+    g_prof.buf = nullptr; g_prof.cap = 0; g_prof.next = 0;
+    return used;
+}
+
 extern "C" int tmix_version(void) { return TMIX_VERSION; }
 extern "C" const char* tmix_last_error_string(void) { return g_err; }
 

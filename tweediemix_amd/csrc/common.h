@@ -47,6 +47,31 @@ void tmix_set_error(const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- in-situ launch timing (tmix_prof_begin / tmix_prof_end): while a host thread has profiling switched on, every
+// instrumented launch (GEMM, conv, attention, GroupNorm) takes the next 8-word slot of the caller's device buffer --
+// also when the launch is being captured into a hipGraph, so replays of that graph time the launches in the schedule the
+// product really runs (two concurrent chains, graph dependencies), which rocprofv3 serialises.  Slot layout, ticks of the
+// 100 MHz s_memrealtime clock: {min start, max end, sum(t1 - t0), sum(t2 - t0), sum(t3 - t0), workgroups, -, -} where per
+// workgroup t0 = entry, t1 = first operands landed, t2 = main loop done, t3 = epilogue stores issued.
+struct TmixProf { unsigned long long* buf; int cap, next; };
+TmixProf& tmix_prof_state();
+static inline unsigned long long* tmix_prof_take() {
+    TmixProf& st = tmix_prof_state();
+    if (!st.buf || st.next >= st.cap) return nullptr;
+    return st.buf + 8 * (size_t)(st.next++);
+}
+__device__ __forceinline__ unsigned long long prof_now() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ unsigned long long prof_enter(unsigned long long* slot) {      // call from ONE thread per workgroup
+    const unsigned long long t = prof_now();
+    atomicMin(slot, t);
+    return t;
+}
+__device__ __forceinline__ void prof_leave(unsigned long long* slot, unsigned long long t0, unsigned long long t1, unsigned long long t2) {
+    const unsigned long long t3 = prof_now();
+    atomicMax(slot + 1, t3);
+    atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, t2 - t0); atomicAdd(slot + 4, t3 - t0); atomicAdd(slot + 5, 1ull);
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids land on
 // the same XCD (hardware places physical id b on XCD b % 8).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

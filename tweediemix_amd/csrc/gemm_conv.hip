@@ -18,6 +18,8 @@
 //
 // MFMA roofline: 2*M*N*K flops per launch against the 2.5 PFLOP/s dense bf16 peak.
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -44,6 +46,8 @@ struct Params {
     float ln_inv_c, ln_eps; int ln_parts;
     // convolution geometry (CONV only)
     int H, Wd, Cin, Ho, Wo, mode, ntaps;
+    unsigned long long* prof;         // in-situ timing slot (common.h) or NULL
+    int wide;                         // bit 0 / 1 / 2: the C / GEGLU / Ct stores may use the LDS-staged 16-byte form
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -61,15 +65,24 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // perfectly (the same work split as 1 loader + 4 math waves: 0.53 us).  So with LW the math waves never touch VMEM in the
 // K loop: the loader streams every K-tile (all (BM+BN)/8 instructions), waits for it with a counted vmcnt, and the
 // per-iteration s_barrier hands it over.
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0>
+// PH = 1 selects the PHASE-OFFSET mainloop (8 waves, two per SIMD): the K loop advances in 32-wide slices through a
+// four-slot LDS ring (two slices stay in flight across every barrier), and each slice is a LOAD segment (LDS-DMA issue for
+// slice s+3, fragment reads of slice s) followed by an MFMA segment (16 x v_mfma_f32_32x32x16_bf16 on a 128x64 wave tile at
+// raised priority).  The second wave of every SIMD (waves 4-7) runs one barrier behind the first, so on each SIMD one wave
+// issues DMA / ds_read while its partner keeps the matrix pipe busy -- an LDS-DMA instruction blocks its OWN wave's issue
+// for ~100 cycles (tools/ubench/dma_issue), which is what held the lock-step loop below at ~50 % of the MFMA rate.
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0>
 // (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
 __global__ void __launch_bounds__((WM * WN + LW) * 64, LW ? 3 : (WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
 gemm_conv_kernel(const Params p) {
+    static_assert(!PH || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
     constexpr int NW = WM * WN;                        // math waves
     constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
     constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
     constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
+    constexpr int SLOT = (BM + BN) * 64;               // PH: one 32-wide K slice of both operands (rows of 64 bytes)
+    constexpr int RING = PH ? 4 * SLOT : NS * STAGE;   // bytes of the staging ring (the fused-LayerNorm block sits behind it)
     constexpr int SW = LW ? 1 : NW;                    // waves that share the staging of a K-tile
     constexpr int IA = BM / 8, IB = BN / 8;            // LDS-DMA instructions per stage (8 rows of 128 bytes each)
     // ... per staging wave; when the waves do not divide them (64x160 over 5 waves) a surplus slot re-stages the last rows
@@ -77,13 +90,16 @@ gemm_conv_kernel(const Params p) {
     constexpr int RA = (IA + SW - 1) / SW, RB = (IB + SW - 1) / SW;
     constexpr int L = RA + RB;
     static_assert(RA >= 1 && RB >= 1 && FM >= 1 && FN >= 1, "tile/wave geometry");
-    static_assert((NS - 2) * L <= 63, "vmcnt immediate");
+    static_assert(PH || (NS - 2) * L <= 63, "vmcnt immediate");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w / WN, wc = w - wr * WN;
+    const bool prof_on = p.prof != nullptr && tid == 0;
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
+    if (prof_on) pt0 = prof_enter(p.prof);
     const bool loader = LW && (w == NW);               // wave-uniform role
     const bool stager = LW ? loader : true;
     const int sw_id = LW ? 0 : w;                      // this wave's slot among the staging waves
@@ -139,7 +155,7 @@ gemm_conv_kernel(const Params p) {
             }
         }
     } else
-    if (stager) {
+    if (stager && !PH) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int idx = slot_w(r);
@@ -163,6 +179,33 @@ gemm_conv_kernel(const Params p) {
         }
     }
     }
+
+    // ---- PH: a slice is (BM + BN) rows of 64 bytes; one LDS-DMA instruction covers 16 rows (lane -> row lane >> 2,
+    // 16-byte position lane & 3), and position q of row r holds source chunk q ^ ((r >> 2) & 3): the 16-lane service
+    // groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then touch 16 distinct 16-byte bank groups.
+    constexpr int PA = PH ? BM / 16 / NW : 1, PB = PH ? BN / 16 / NW : 1;      // DMA instructions per wave per slice
+    unsigned phA[PA], phW[PB];
+    if constexpr (PH) {
+        const unsigned ch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 8);  // swizzled source chunk (elements)
+#pragma unroll
+        for (int r = 0; r < PA; ++r) {
+            int m = m0 + (r * NW + w) * 16 + (lane >> 2); if (m > p.M - 1) m = p.M - 1;
+            phA[r] = ((unsigned)m * (unsigned)p.lda + ch) * 2u;
+        }
+#pragma unroll
+        for (int r = 0; r < PB; ++r) {
+            int n = n0 + (r * NW + w) * 16 + (lane >> 2); if (n > p.N - 1) n = p.N - 1;
+            phW[r] = ((unsigned)n * (unsigned)p.ldw + ch) * 2u;
+        }
+    }
+    auto ph_stage = [&](int slot, int s) {
+        char* sA = smem + slot * SLOT;
+        char* sW = sA + BM * 64;
+#pragma unroll
+        for (int r = 0; r < PA; ++r) blds16(rsA, phA[r], (unsigned)s * 64u, sA + (r * NW + w) * 1024);
+#pragma unroll
+        for (int r = 0; r < PB; ++r) blds16(rsW, phW[r], (unsigned)s * 64u, sW + (r * NW + w) * 1024);
+    };
 
     const int nk = p.K / BK;
     int tap = 0, cc = 0;                              // conv K-tile cursor: tap (0..8), 64-channel chunk
@@ -233,7 +276,7 @@ gemm_conv_kernel(const Params p) {
     // a fixed order -> scheduling-independent) and the weight column sum are requested here, and reduced once the
     // prologue's K-tiles are in flight (ln_reduce), so their latency rides under the prologue.  The results go to a
     // small LDS block behind the staging ring, already in MFMA-operand form (see part 2).
-    uint4* ln_mfrag = (uint4*)(smem + NS * STAGE);    // [BM] -mean pieces, [BN] colsum pieces, then float rstd[BM]
+    uint4* ln_mfrag = (uint4*)(smem + RING);          // [BM] -mean pieces, [BN] colsum pieces, then float rstd[BM]
     uint4* ln_cfrag = ln_mfrag + BM;
     float* ln_rs = (float*)(ln_cfrag + BN);
     constexpr int PU = 16;
@@ -326,7 +369,7 @@ gemm_conv_kernel(const Params p) {
 
     // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
     const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
-    const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU;
+    const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU && !(p.wide & 1);
     constexpr bool PREF = FM * FN <= 4;               // large wave tiles have no registers to spare for it
     uint2 rres[PREF ? FM : 1][PREF ? FN : 1][4];
     auto prefetch_residual = [&]() {
@@ -344,10 +387,86 @@ gemm_conv_kernel(const Params p) {
         }
     };
     // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
+    if constexpr (PH) {
+        constexpr int PL = PA + PB;                    // this wave's DMA instructions per slice
+        static_assert(2 * PL <= 63, "vmcnt immediate");
+        const int ns = p.K / 32;
+        const int offA4 = (wr * TM + l31) * 64, offW4 = BM * 64 + (wc * TN + l31) * 64;
+        const int f4 = (lane >> 2) & 3;                // (row >> 2) & 3 of fragment row base + (lane & 31)
+        const int q0 = ((0 + lhi) ^ f4) << 4, q1 = ((2 + lhi) ^ f4) << 4;      // k-step 0 / 1 of the slice
+        const int grp = w >> 2;                        // waves 4-7 (the second wave of each SIMD) run one barrier behind
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < ns) ph_stage(s, s);
+        ln_reduce();
+        if (ns >= 3) wait_vmcnt<2 * PL>(); else if (ns == 2) wait_vmcnt<PL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (prof_on) pt1 = prof_now();
+        if (grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        // One slice: LOAD segment (fragment reads of slice s; the wait that makes slice s + 1 visible), barrier, MFMA
+        // segment, barrier.  The LDS-DMA instructions of slice s + 3 are issued INSIDE the MFMA cluster, one after every
+        // fourth MFMA: among MFMAs a DMA costs ~60 issue cycles and about half of it hides behind the 32-cycle matrix
+        // op, while beside the ds_reads of the LOAD segment each cost 100-185 cycles and made that segment (not the MFMA
+        // segment of the partner wave) the length of every barrier interval.  Its ring slot is the one slice s - 1 was
+        // read from, released two barriers ago.
+        auto slice = [&](int s, auto stage_tag) {
+            constexpr bool ST = decltype(stage_tag)::value;
+            const char* pa = smem + (s & 3) * SLOT + offA4;
+            const char* pw = smem + (s & 3) * SLOT + offW4;
+            frag_ab a[2][FM], b[2][FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) { a[0][i] = *(const frag_ab*)(pa + i * 32 * 64 + q0); a[1][i] = *(const frag_ab*)(pa + i * 32 * 64 + q1); }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { b[0][j] = *(const frag_ab*)(pw + j * 32 * 64 + q0); b[1][j] = *(const frag_ab*)(pw + j * 32 * 64 + q1); }
+            // slice s + 1 must have landed (for every wave) before the barrier in front of its first reader; in flight
+            // here: slices s + 1 and s + 2 (slice s + 3 is issued below)
+            if (s + 2 < ns) wait_vmcnt<PL>(); else wait_vmcnt<0>();
+            if (PREF && s == ns - 1 && Rb && plain_epi) prefetch_residual();     // rides under the last MFMA segment
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA segment
+            __builtin_amdgcn_s_setprio(1);
+            char* sA = smem + ((s + 3) & 3) * SLOT;
+            char* sW = sA + BM * 64;
+            constexpr int NMF = 2 * FM * FN, GAP = NMF / PL;        // one DMA after every GAP-th MFMA
+            int issued = 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
+                        const int idx = (kk * FM + i) * FN + j;
+                        if constexpr (ST) {
+                            if (idx % GAP == (GAP > 1 ? 1 : 0) && issued < PL) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (issued < PA) blds16(rsA, phA[issued], (unsigned)(s + 3) * 64u, sA + (issued * NW + w) * 1024);
+                                else             blds16(rsW, phW[issued - PA], (unsigned)(s + 3) * 64u, sW + ((issued - PA) * NW + w) * 1024);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++issued;
+                            }
+                        }
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        };
+        int s = 0;
+        for (; s + 3 < ns; ++s) slice(s, std::true_type{});
+        for (; s < ns; ++s) slice(s, std::false_type{});
+        if (!grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    } else
     if constexpr (LW) {
         ln_reduce();                                   // ---- math waves: LDS reads + MFMA only
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (prof_on) pt1 = prof_now();
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
@@ -364,6 +483,7 @@ gemm_conv_kernel(const Params p) {
     if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (prof_on) pt1 = prof_now();
     int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + NS - 1 < nk;
@@ -378,6 +498,7 @@ gemm_conv_kernel(const Params p) {
     }
     }
 
+    if (prof_on) pt2 = prof_now();
     // ---------------------------------------------------------------- fused LayerNorm (consumer side), part 2
     // A was the raw row x; with W' = W*gamma:  Linear(LN(x))[m][n] = rstd_m * (acc[m][n] - mean_m * colsum_n) + t_n
     // (t_n arrives as the bias).  The rank-1 term -mean_m * colsum_n is one more MFMA k-step per fragment, fed from
@@ -415,9 +536,55 @@ gemm_conv_kernel(const Params p) {
 
     // 32x32 accumulator: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    // ---- LDS-staged ("wide") stores.  In the accumulator layout a lane owns 4 consecutive outputs of ONE row, so a store
+    // instruction scatters 64 x 8 bytes over 32 rows: 32 partial-line requests per instruction, and the epilogue of a
+    // 256 x 256 tile took 14-24 us (a quarter to a half of the whole workgroup; tools/gemm_lab `tl`).  The staging ring is
+    // free by now: each wave copies a 32-row block of its tile to a private LDS patch (rows padded by 16 bytes), reads it
+    // back row-major -- 8 consecutive outputs per lane, 4-8 lanes per row -- and does bias / LayerNorm scale / activation /
+    // residual there, so residual loads and C stores are 16 bytes per lane and 64-128 contiguous bytes per row.  Values and
+    // operation order per element are those of the narrow path (bit-identical C); only the row statistics add in a new order.
+    constexpr int STG_MAX = 32 * (2 * 32 * 4 + 16);               // bytes of LDS patch per wave (largest chunk: 64 fp32 columns)
     if (trans) {
         if constexpr (FM == FN && TM == TN) {
             bf16_t* Ct = p.Ct + (int64_t)bz * p.strideCt;
+            if (p.wide & 4) {
+                constexpr int CF = (FN % 2 == 0) ? 2 : 1, SR = CF * 64 + 16, LPR = CF * 4, RPI = 64 / LPR, NP = 32 / RPI;
+                char* stg = smem + w * STG_MAX;
+                const int rr = lane / LPR, cc = (lane % LPR) * 8;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {             // W fragment: 32 rows of Ct
+                    const int nl = n0 + wc * TN + i * 32 + l31;
+                    const float bv = (bias && nl < p.N) ? bias[nl] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < FN / CF; ++c) {
+#pragma unroll
+                        for (int jj = 0; jj < CF; ++jj)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int j = c * CF + jj, ml = wr * TM + j * 32 + g * 8 + lhi * 4;
+                                const float4 rs = p.ln_stats ? *(const float4*)(ln_rs + ml) : make_float4(1.f, 1.f, 1.f, 1.f);
+                                uint2 v;
+                                v.x = pack_bf2(fmaf(acc[i][j][g * 4 + 0], rs.x, bv), fmaf(acc[i][j][g * 4 + 1], rs.y, bv));
+                                v.y = pack_bf2(fmaf(acc[i][j][g * 4 + 2], rs.z, bv), fmaf(acc[i][j][g * 4 + 3], rs.w, bv));
+                                *(uint2*)(stg + l31 * SR + (jj * 32 + g * 8 + lhi * 4) * 2) = v;
+                            }
+#pragma unroll
+                        for (int ps = 0; ps < NP; ++ps) {
+                            const int r = ps * RPI + rr, n = n0 + wc * TN + i * 32 + r, m = m0 + wr * TM + c * CF * 32 + cc;
+                            const uint4 v = *(const uint4*)(stg + r * SR + cc * 2);
+                            if (n >= p.N || m >= p.M) continue;
+                            bf16_t* dst = Ct + (int64_t)(n - p.n_trans_begin) * p.ldct + m;
+                            if (m + 8 <= p.M) *(uint4*)dst = v;
+                            else {
+                                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                                for (int k = 0; k < 8 && m + k < p.M; ++k) dst[k] = (bf16_t)(u[k >> 1] >> ((k & 1) * 16));
+                            }
+                        }
+                    }
+                }
+                if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {                 // W fragment (output row of Ct)
                 const int n = n0 + wc * TN + i * 32 + l31;
@@ -446,6 +613,7 @@ gemm_conv_kernel(const Params p) {
                     }
             }
         }
+        if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
         return;
     }
 
@@ -453,6 +621,49 @@ gemm_conv_kernel(const Params p) {
     if (p.epilogue == TMIX_EPI_GEGLU) {
         // weight rows are interleaved in 16-row groups [value_j | gate_j]: within a 32-row fragment, accumulator
         // register groups g=0,1 (rows 0-15) are the value half and g=2,3 (rows 16-31) the gate half.
+        if (p.wide & 2) {
+            char* stg = smem + w * STG_MAX;
+            auto chunk = [&](int i, int j0, auto cf_tag) {       // CF fragments -> CF * 16 output columns of one 32-row block
+                constexpr int CF = decltype(cf_tag)::value, OC = CF * 16, SR = OC * 2 + 16, LPR = OC / 8, RPI = 64 / LPR, NP = 32 / RPI;
+                const int rr = lane / LPR, cc = (lane % LPR) * 8;
+#pragma unroll
+                for (int jj = 0; jj < CF; ++jj) {
+                    const int j = j0 + jj, nb = n0 + wc * TN + j * 32;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int nv = nb + g * 8 + lhi * 4;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
+                            if (bias && nb < p.N) { a = fmaf(a, rs_row[i], bias[nv + r]); gt = fmaf(gt, rs_row[i], bias[nv + 16 + r]); }
+                            else { a *= rs_row[i]; gt *= rs_row[i]; }
+                            o[r] = a * gelu_erf_f(gt);
+                        }
+                        uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                        *(uint2*)(stg + l31 * SR + (jj * 16 + g * 8 + lhi * 4) * 2) = v;
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int r = ps * RPI + rr, m = m0 + wr * TM + i * 32 + r;
+                    const uint4 v = *(const uint4*)(stg + r * SR + cc * 2);
+                    const int nb = n0 + wc * TN + (j0 + cc / 16) * 32;              // weight row of the fragment this lane's columns come from
+                    if (m >= p.M || nb >= p.N) continue;
+                    *(uint4*)(Cb + (int64_t)m * p.ldc + (n0 + wc * TN) / 2 + j0 * 16 + cc) = v;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                constexpr int C4 = FN / 4, R4 = FN % 4;
+#pragma unroll
+                for (int c = 0; c < C4; ++c) chunk(i, c * 4, std::integral_constant<int, 4>{});
+                if constexpr (R4 >= 2) chunk(i, C4 * 4, std::integral_constant<int, 2>{});
+                if constexpr (R4 & 1) chunk(i, FN - 1, std::integral_constant<int, 1>{});
+            }
+            if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wr * TM + i * 32 + l31;
@@ -477,12 +688,150 @@ gemm_conv_kernel(const Params p) {
                 }
             }
         }
+        if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
         return;
     }
     // LayerNorm producer side: {sum, sum of squares} of every row of this tile AS STORED (bf16-rounded), reduced over
     // the wave's fragments, the lane pair and the WG's wave columns in a fixed order, then written (not accumulated)
     // to stats_out[tile_n][m] -- one partial per column tile; the consumer adds the tiles_n partials.
     float2* sto = p.stats_out ? (float2*)(p.stats_out + (int64_t)bz * p.strideStatsOut) : nullptr;
+    if (p.wide & 1) {
+        char* stg = smem + w * STG_MAX;
+        float2* redw = (float2*)(smem + NW * STG_MAX);           // [WN][BM] row-statistics exchange, behind the patches
+        const bool f32out = p.epilogue == TMIX_EPI_F32OUT;
+        // row statistics: partial {sum, sum of squares} per (32-row block, pass); the 64-column chunks (8 lanes per row, 4
+        // passes of 8 rows) and a trailing 32-column chunk (4 lanes per row, 2 passes of 16 rows) map lanes to rows differently
+        float sa1[FM][4], sa2[FM][4], sb1[FM][2], sb2[FM][2];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sa1[i][q] = 0.f; sa2[i][q] = 0.f; }
+            sb1[i][0] = sb1[i][1] = sb2[i][0] = sb2[i][1] = 0.f;
+        }
+        auto chunk = [&](int j0, auto cf_tag) {                  // CF fragments = CF * 32 fp32 columns of every 32-row block
+            constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, SR = CW * 4 + 16, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
+            const int rr = lane / LPR, cc = (lane % LPR) * 8;
+            const int nc = n0 + wc * TN + j0 * 32 + cc;
+            const bool ncok = nc < p.N;
+            float bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = 0.f;
+            if (bias && ncok) {
+                const float4 b0 = *(const float4*)(bias + nc), b1 = *(const float4*)(bias + nc + 4);
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int mb = m0 + wr * TM + i * 32;
+                uint4 rv[NP];
+                if (Rb) {
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const int m = mb + ps * RPI + rr;
+                        if (m < p.M && ncok) rv[ps] = *(const uint4*)(Rb + (int64_t)m * p.ldr + nc);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < CF; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(float4*)(stg + l31 * SR + (jj * 32 + g * 8 + lhi * 4) * 4) =
+                            make_float4(acc[i][j0 + jj][g * 4 + 0], acc[i][j0 + jj][g * 4 + 1], acc[i][j0 + jj][g * 4 + 2], acc[i][j0 + jj][g * 4 + 3]);
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int r = ps * RPI + rr, m = mb + r;
+                    const float4 v0 = *(const float4*)(stg + r * SR + cc * 4), v1 = *(const float4*)(stg + r * SR + cc * 4 + 16);
+                    if (m >= p.M || !ncok) continue;
+                    float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    if (bias) { const float rs = p.ln_stats ? ln_rs[wr * TM + i * 32 + r] : 1.f;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) o[k] = fmaf(o[k], rs, bv[k]); }
+                    else if (p.ln_stats) { const float rs = ln_rs[wr * TM + i * 32 + r];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) o[k] *= rs; }
+                    if (p.rgb) {
+                        const float* rg = p.rgb + (int64_t)(m / p.rows_per_group) * p.N + nc;
+                        const float4 b0 = *(const float4*)rg, b1 = *(const float4*)(rg + 4);
+                        o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+                    }
+                    if (p.epilogue == TMIX_EPI_GELU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = gelu_erf_f(o[k]);
+                    } else if (p.epilogue == TMIX_EPI_QUICKGELU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = o[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * o[k]));
+                    }
+                    if (Rb) {
+                        const unsigned u[4] = {rv[ps].x, rv[ps].y, rv[ps].z, rv[ps].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { o[2 * k] += bf2f((bf16_t)(u[k] & 0xffff)); o[2 * k + 1] += bf2f((bf16_t)(u[k] >> 16)); }
+                    }
+                    if (f32out) {
+                        float* dst = (float*)p.C + (int64_t)bz * p.strideC + (int64_t)m * p.ldc + nc;
+                        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    } else {
+                        uint4 v;
+                        v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
+                        *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
+                        if (sto) {                                 // statistics of the values AS STORED
+                            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+                                a1 += lo + hi; a2 = fmaf(lo, lo, a2); a2 = fmaf(hi, hi, a2);
+                            }
+                            if constexpr (CF == 2) { sa1[i][ps] += a1; sa2[i][ps] += a2; } else { sb1[i][ps] += a1; sb2[i][ps] += a2; }
+                        }
+                    }
+                }
+            }
+        };
+        // chunks of two fragments (64 columns: 8 lanes x 16 bytes per row), a last single one when FN is odd
+        constexpr int C2 = FN / 2;
+#pragma unroll
+        for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{});
+        if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{});
+        if (sto) {
+            // a row's partials sit in the lanes that stored its columns: reduce over those lanes (fixed butterfly order), the
+            // group's first lane owns the row; the 32-column chunk's owners then add to the same slot (same wave: LDS in order)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (C2 > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float a1 = sa1[i][q], a2 = sa2[i][q];
+#pragma unroll
+                        for (int off = 1; off < 8; off <<= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
+                        if ((lane & 7) == 0) redw[wc * BM + wr * TM + i * 32 + q * 8 + (lane >> 3)] = make_float2(a1, a2);
+                    }
+                }
+                if constexpr (FN & 1) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float b1 = sb1[i][q], b2 = sb2[i][q];
+#pragma unroll
+                        for (int off = 1; off < 4; off <<= 1) { b1 += __shfl_xor(b1, off); b2 += __shfl_xor(b2, off); }
+                        if ((lane & 3) == 0) {
+                            float2* dst = redw + wc * BM + wr * TM + i * 32 + q * 16 + (lane >> 2);
+                            if constexpr (C2 > 0) { const float2 t = *dst; *dst = make_float2(t.x + b1, t.y + b2); }
+                            else *dst = make_float2(b1, b2);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float2 t = redw[tid];
+#pragma unroll
+                for (int c = 1; c < WN; ++c) { const float2 u = redw[c * BM + tid]; t.x += u.x; t.y += u.y; }
+                sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
+            }
+        }
+        if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+        return;
+    }
     float2* red = (float2*)smem;                                // [WN][BM]: the staging ring is free by now
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -546,6 +895,7 @@ gemm_conv_kernel(const Params p) {
             sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
         }
     }
+    if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
 }
 
 // ------------------------------------------------------------------------------------------- launch
@@ -567,13 +917,15 @@ struct TileCfg { int bm, bn; };
 // 256x256 runs 320 (a quarter-full second round); 128x320 over four waves was tried and lost to 128x160 everywhere
 // 15 = 32x160 over five waves (each 32x32): 1024 x 1280 -- one batch row per chain, the CFG-pair calls -- is 256 tiles
 // (a 5-deep ring for 13 measured the same as the 4-deep one)
-constexpr int NUM_CFG = 15;
+// 16 = 256x256, 17 = 256x128 with the PHASE-OFFSET mainloop (PH: eight waves, K slices of 32 through a four-slot ring, the
+// second wave of every SIMD one barrier behind the first; GEMM only, no transposed region)
+constexpr int NUM_CFG = 17;
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0>
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
-    constexpr int SMEM = NS * (BM + BN) * 128 + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
+    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
     static bool attr_set = false;   // idempotent; racing threads set the same value
-    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW>;
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -583,6 +935,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     p.group_m = BM >= 256 ? 4 : 8;
     if (BM >= 256 && BN >= 256) p.group_m = 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
+    p.prof = tmix_prof_take();
     kern<<<grid, (WM * WN + LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
@@ -599,7 +952,7 @@ template <int CONV>
 int launch(Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
     if (p.n_trans_begin >= 0) {                                                // transposed stores need square wave tiles
-        if (cfg == 4 || cfg == 5 || cfg == 7 || cfg >= 12) cfg = 2;
+        if (cfg == 4 || cfg == 5 || cfg == 7 || cfg >= 12) cfg = 2;     // (incl. the phase-offset tilings 16, 17)
         if (cfg == 6 && (p.n_trans_begin % 256)) cfg = 2;                     // the boundary must fall on a tile edge (N = 3 x 320: 640)
         if (cfg == 8 || cfg == 11) cfg = 9;
     }
@@ -615,6 +968,10 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
     case 13: return launch_cfg<64, 160, 1, 5, 4, CONV>(p, batch, st);
     case 14: return launch_cfg<256, 320, 4, 2, 2, CONV>(p, batch, st);
     case 15: return launch_cfg<32, 160, 1, 5, 4, CONV>(p, batch, st);
+    case 16: if constexpr (CONV) return launch_cfg<256, 256, 2, 4, 2, CONV>(p, batch, st);
+             else { if (p.K % 32) break; return launch_cfg<256, 256, 2, 4, 4, 0, 0, 1>(p, batch, st); }
+    case 17: if constexpr (CONV) return launch_cfg<256, 128, 4, 2, 3, CONV>(p, batch, st);
+             else return launch_cfg<256, 128, 4, 2, 4, 0, 0, 1>(p, batch, st);
     default: break;
     }
     // loader-wave variants exist for the plain GEMM only: the im2col gather's per-row offset tables do not fit the loader's
@@ -641,7 +998,8 @@ int launch(Params& p, int batch, int cfg, hipStream_t st) {
 
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
-                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160}};
+                                              {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160},
+                                              {256, 256}, {256, 128}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;
@@ -693,6 +1051,16 @@ extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) {
     p.stats_out = d->row_stats_out; p.strideStatsOut = d->strideStatsOut; p.ldStatsOut = d->ldStatsOut;
     p.ln_stats = d->ln_stats; p.strideLnStats = d->strideLnStats; p.ldLnStats = d->ldLnStats; p.ln_parts = d->ln_parts;
     p.ln_colsum = d->ln_colsum; p.strideLnColsum = d->strideLnColsum; p.ln_inv_c = d->ln_inv_c; p.ln_eps = d->ln_eps;
+    // LDS-staged 16-byte stores need 16-byte aligned rows (the narrow 8-byte form stays as the fallback for odd strides)
+    const bool c16 = d->C && aligned16(d->C) && (d->ldc % 8) == 0 && (d->strideC % 8) == 0;
+    const bool r16 = !d->residual || (aligned16(d->residual) && (d->ldr % 8) == 0 && (d->strideR % 8) == 0);
+    p.wide = 0;
+    if (!getenv("TMIX_NARROW_EPILOGUE")) {
+        if (d->epilogue == TMIX_EPI_GEGLU) { if (c16) p.wide |= 2; }
+        else if (d->epilogue == TMIX_EPI_F32OUT) { if (aligned16(d->C) && (d->ldc % 4) == 0 && (d->strideC % 4) == 0 && (d->N % 8) == 0) p.wide |= 1; }
+        else if (c16 && r16 && (d->N % 8) == 0) p.wide |= 1;
+        if (has_trans && aligned16(d->Ct) && (d->ldct % 8) == 0 && (d->strideCt % 8) == 0) p.wide |= 4;
+    }
     return launch<0>(p, d->batch, d->tile_cfg, (hipStream_t)stream);
 }
 
@@ -725,5 +1093,6 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.epilogue = TMIX_EPI_NONE;
     p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
     p.bytesW = (unsigned)((int64_t)d->Cout * p.ntaps * d->Cin * 2);
+    p.wide = (!getenv("TMIX_NARROW_EPILOGUE") && aligned16(d->Y) && (d->Cout % 8) == 0 && (!d->residual || aligned16(d->residual))) ? 1 : 0;
     return launch<1>(p, 1, d->tile_cfg, (hipStream_t)stream);
 }

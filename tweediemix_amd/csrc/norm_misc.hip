@@ -48,8 +48,10 @@ __host__ __device__ inline int gn_chunks(int64_t HW) {
 
 // partial sums per (batch, chunk of pixels, group): ws[((b*chunks + ch)*groups + g)*2 + {0,1}]
 __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
-                                                       float* __restrict__ ws, int64_t HW, int groups, int chunks) {
+                                                       float* __restrict__ ws, int64_t HW, int groups, int chunks,
+                                                       unsigned long long* prof) {
     __shared__ float s_sum[GN_MAX_C], s_sq[GN_MAX_C];
+    if (prof && threadIdx.x == 0) prof_enter(prof);            // in-situ timing (common.h): the norm's three launches share a slot
     const int C = C1 + C2, nvec = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int64_t ppc = (HW + chunks - 1) / chunks;
@@ -128,8 +130,10 @@ __device__ __forceinline__ float silu_fast(float x) {     // x * sigmoid(x) with
 }
 
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
-                                                       bf16_t* __restrict__ Y, const float2* __restrict__ ss, int64_t HW, int silu) {
+                                                       bf16_t* __restrict__ Y, const float2* __restrict__ ss, int64_t HW, int silu,
+                                                       unsigned long long* prof) {
     __shared__ float2 s_ss[GN_MAX_C];
+    const unsigned long long pt0 = (prof && threadIdx.x == 0) ? prof_now() : 0;
     const int C = C1 + C2, nvec = C >> 3;
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int c = tid; c < C; c += 256) s_ss[c] = ss[(int64_t)b * C + c];
@@ -169,6 +173,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
             }
         }
     }
+    if (prof && threadIdx.x == 0) prof_leave(prof, pt0, pt0, pt0);
 }
 
 // ------------------------------------------------------------------------------ LayerNorm
@@ -468,14 +473,15 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     if (!aligned16(X1) || (X2 && !aligned16(X2)) || !aligned16(Y)) TMIX_FAIL(TMIX_EALIGN, "groupnorm: pointers must be 16-byte aligned");
     const int chunks = gn_chunks(HW);
     hipStream_t st = (hipStream_t)stream;
-    gn_stats_kernel<<<dim3(chunks, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, ws, HW, groups, chunks);
+    unsigned long long* prof = tmix_prof_take();
+    gn_stats_kernel<<<dim3(chunks, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, ws, HW, groups, chunks, prof);
     TMIX_LAUNCH_CHECK();
     // ws layout: [B*chunks*groups*2] partial sums | [B*C] float2 scale/shift
     float2* ss = (float2*)(ws + (int64_t)B * GN_T * groups * 2);
     gn_finalize_kernel<<<dim3(groups, B), 64, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
     TMIX_LAUNCH_CHECK();
     int64_t nb = (HW * (C / 8) + GN_APPLY_ITEMS - 1) / GN_APPLY_ITEMS; if (nb < 1) nb = 1; if (nb > GN_APPLY_MAXB) nb = GN_APPLY_MAXB;
-    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu);
+    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }

@@ -28,11 +28,21 @@ template <int DT> __device__ __forceinline__ float cfg(float eu, float ec, float
     return rnd<DT>(eu + gd);
 }
 
-template <int DT, int MODE>
+// DEV = 1: the step coefficients come from a device buffer prm = {t, sa, s1, sa_next, s1_next, is_last, g} (so ONE captured
+// launch serves every timestep of a hipGraph replay) and blockIdx.y walks co-batched seeds (x / out: [seeds][n], eps:
+// [seeds][rows][n], masks: [seeds][K][hw] or shared).  x may alias out_x: element i is read before it is written.
+template <int DT, int MODE, int DEV = 0>
 __global__ void __launch_bounds__(256)
-tweedie_step_kernel(const float* __restrict__ x, const typename EpsT<DT>::T* __restrict__ eps,
-                    const float* __restrict__ masks, float* __restrict__ out_x, float* __restrict__ out_x0,
-                    int K, int64_t n, int64_t hw, float g, float sa, float s1, float sa_n, float s1_n, int is_last) {
+tweedie_step_kernel(const float* x, const typename EpsT<DT>::T* __restrict__ eps,
+                    const float* __restrict__ masks, float* out_x, float* __restrict__ out_x0,
+                    int K, int64_t n, int64_t hw, float g, float sa, float s1, float sa_n, float s1_n, int is_last,
+                    const float* __restrict__ prm = nullptr, int rows = 0, int64_t mask_seed_stride = 0) {
+    if constexpr (DEV) {
+        sa = prm[1]; s1 = prm[2]; sa_n = prm[3]; s1_n = prm[4]; is_last = prm[5] != 0.0f; g = prm[6];
+        const int64_t sd = blockIdx.y;
+        x += sd * n; out_x += sd * n; eps += sd * rows * n; masks += sd * mask_seed_stride;
+        if (out_x0) out_x0 += sd * n;
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float xv = x[i];
@@ -81,6 +91,39 @@ int launch(const float* x, const void* eps, const float* masks, float* out_x, fl
     }
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
+}
+
+template <int DT>
+int launch_dev(const float* x, const void* eps, const float* masks, int64_t mss, float* out_x, float* out_x0, int K, int64_t n,
+               int64_t hw, int mode, int rows, int seeds, const float* prm, hipStream_t st) {
+    typedef typename EpsT<DT>::T T;
+    int64_t bx = (n + 255) / 256; if (bx > 2048) bx = 2048;
+    const dim3 grid((unsigned)bx, (unsigned)seeds);
+    const T* e = (const T*)eps;
+    switch (mode) {
+    case TMIX_STEP_FUSION:
+        tweedie_step_kernel<DT, TMIX_STEP_FUSION, 1><<<grid, 256, 0, st>>>(x, e, masks, out_x, out_x0, K, n, hw, 0.f, 1.f, 0.f, 1.f, 0.f, 0, prm, rows, mss); break;
+    case TMIX_STEP_PLAIN:
+        tweedie_step_kernel<DT, TMIX_STEP_PLAIN, 1><<<grid, 256, 0, st>>>(x, e, masks, out_x, out_x0, K, n, hw, 0.f, 1.f, 0.f, 1.f, 0.f, 0, prm, rows, mss); break;
+    default:
+        tweedie_step_kernel<DT, TMIX_STEP_RESAMPLE, 1><<<grid, 256, 0, st>>>(x, e, masks, out_x, out_x0, K, n, hw, 0.f, 1.f, 0.f, 1.f, 0.f, 0, prm, rows, mss); break;
+    }
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+// head of a captured denoising step: every seed's latent is broadcast over its UNet batch rows and the timestep
+// (prm[0]) is written to the UNet's per-row timestep input -- fusion_sampling.py:324-327,336 (`latent_model_input`, `t`)
+__global__ void __launch_bounds__(256)
+step_prologue_kernel(const float* __restrict__ x, float* __restrict__ latent, float* __restrict__ t_dev,
+                     const float* __restrict__ prm, int rows, int64_t n) {
+    const int64_t sd = blockIdx.y;
+    const float4* src = (const float4*)(x + sd * n);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        for (int r = 0; r < rows; ++r) ((float4*)(latent + (sd * rows + r) * n))[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < rows) t_dev[sd * rows + threadIdx.x] = prm[0];
 }
 
 // ------------------------------------------------------------------ video sampler (I2VGen-XL loop, config #5)
@@ -186,4 +229,35 @@ extern "C" int tmix_fused_tweedie_step(const float* x, const void* eps, int eps_
     case TMIX_BF16: return launch<TMIX_BF16>(x, eps, masks, out_x, out_x0, K, n, hw, mode, g, sa, s1, sa_next, s1_next, is_last, st);
     }
     TMIX_FAIL(TMIX_EINVAL, "tweedie_step: bad eps dtype %d", eps_dtype);
+}
+
+extern "C" int tmix_fused_tweedie_step_dev(const float* x, const void* eps, int eps_dtype, const float* masks,
+                                           int64_t mask_seed_stride, float* out_x, float* out_x0, int K, int channels,
+                                           int64_t hw, int mode, int rows, int seeds, const float* params, void* stream) {
+    if (!x || !eps || !out_x || !params) TMIX_FAIL(TMIX_EINVAL, "tweedie_step_dev: null pointer");
+    if (mode < TMIX_STEP_FUSION || mode > TMIX_STEP_RESAMPLE) TMIX_FAIL(TMIX_EINVAL, "tweedie_step_dev: bad mode %d", mode);
+    if (mode == TMIX_STEP_FUSION && (!masks || K < 1)) TMIX_FAIL(TMIX_EINVAL, "tweedie_step_dev: FUSION needs masks and K>=1");
+    if (mode == TMIX_STEP_RESAMPLE && K < 1) TMIX_FAIL(TMIX_EINVAL, "tweedie_step_dev: RESAMPLE needs K>=1");
+    if (channels < 1 || hw < 1 || seeds < 1 || seeds > 65535) TMIX_FAIL(TMIX_ESHAPE, "tweedie_step_dev: channels=%d hw=%lld seeds=%d", channels, (long long)hw, seeds);
+    const int need = mode == TMIX_STEP_PLAIN ? 2 : K + 1;
+    if (rows < need) TMIX_FAIL(TMIX_ESHAPE, "tweedie_step_dev: mode %d needs %d eps rows per seed, got %d", mode, need, rows);
+    const int64_t n = (int64_t)channels * hw;
+    hipStream_t st = (hipStream_t)stream;
+    switch (eps_dtype) {
+    case TMIX_F32:  return launch_dev<TMIX_F32>(x, eps, masks, mask_seed_stride, out_x, out_x0, K, n, hw, mode, rows, seeds, params, st);
+    case TMIX_F16:  return launch_dev<TMIX_F16>(x, eps, masks, mask_seed_stride, out_x, out_x0, K, n, hw, mode, rows, seeds, params, st);
+    case TMIX_BF16: return launch_dev<TMIX_BF16>(x, eps, masks, mask_seed_stride, out_x, out_x0, K, n, hw, mode, rows, seeds, params, st);
+    }
+    TMIX_FAIL(TMIX_EINVAL, "tweedie_step_dev: bad eps dtype %d", eps_dtype);
+}
+
+extern "C" int tmix_step_prologue(const float* x, float* latent, float* t_dev, const float* params, int seeds, int rows,
+                                  int64_t n, void* stream) {
+    if (!x || !latent || !t_dev || !params) TMIX_FAIL(TMIX_EINVAL, "step_prologue: null pointer");
+    if (seeds < 1 || seeds > 65535 || rows < 1 || rows > 256 || n < 4 || (n & 3)) TMIX_FAIL(TMIX_ESHAPE, "step_prologue: seeds=%d rows=%d n=%lld (n %% 4 == 0)", seeds, rows, (long long)n);
+    if (!aligned16(x) || !aligned16(latent)) TMIX_FAIL(TMIX_EALIGN, "step_prologue: x / latent must be 16-byte aligned");
+    int64_t bx = (n / 4 + 255) / 256; if (bx > 256) bx = 256;
+    step_prologue_kernel<<<dim3((unsigned)bx, (unsigned)seeds), 256, 0, (hipStream_t)stream>>>(x, latent, t_dev, params, rows, n);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
 }

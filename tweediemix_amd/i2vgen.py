@@ -220,6 +220,7 @@ class I2VPlan(UNetPlan):
         self.ops, self.keep, self.arena = [], [], _Arena(dev)
         self.flops = self.gemm_flops = 0
         self.launches = {"gemm": [], "conv": [], "attn": []}
+        self.op_meta = {}
         self._tunable, self._ln_links, self._vt = [], [], {}
         self.kv = _KV(W, context, frames)
         self.x_in = torch.zeros(B, 2 * cfg.in_channels, h, w, device=dev, dtype=F32)

@@ -15,8 +15,8 @@ F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
 CONV_S1, CONV_S2, CONV_UP2, CONV_T3, CONV_S2A = 0, 1, 2, 3, 4
-TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 15, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
-TILE_CANDIDATES = (1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15)                  # what the autotuner times by default
+TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 17, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
+TILE_CANDIDATES = (1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15, 16, 17)          # what the autotuner times by default (16, 17: phase-offset mainloop)
 TILE_EXCLUSIVE = (13, 14, 15)                                  # one workgroup per CU over the whole chip: not beside a sibling chain
 TILE_LW = (8, 9, 10, 11)                                     # added with TMIX_TUNE_LW=1 (GEMM only)
 
@@ -52,8 +52,13 @@ SIGNATURES = {
     "tmix_version": (C.c_int, []),
     "tmix_last_error_string": (C.c_char_p, []),
     "tmix_check_device": (C.c_int, []),
+    "tmix_prof_begin": (C.c_int, [vp, C.c_int]),
+    "tmix_prof_end": (C.c_int, []),
     "tmix_fused_tweedie_step": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, i64, C.c_int,
                                           f32, f32, f32, f32, f32, C.c_int, vp]),
+    "tmix_fused_tweedie_step_dev": (C.c_int, [vp, vp, C.c_int, vp, i64, vp, vp, C.c_int, C.c_int, i64, C.c_int, C.c_int,
+                                              C.c_int, vp, vp]),
+    "tmix_step_prologue": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, i64, vp]),
     "tmix_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "tmix_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "tmix_conv_in": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -7,12 +7,17 @@ Same method names, argument meaning and step semantics as fusion_generation/fusi
 * phase decisions and alpha tables on the host as plain ints/floats (the reference syncs the device
   several times per step through `.item()` and CPU-tensor indexing),
 * one UNet launch plan per call kind (fusion / start / plain), each with its own cross-attention K/V
-  cache, optionally captured into a hipGraph,
-* CFG + Tweedie + blend + DDIM done by ONE kernel (tmix_fused_tweedie_step).
+  cache,
+* CFG + Tweedie + blend + DDIM done by ONE kernel (tmix_fused_tweedie_step_dev) that updates the latent
+  state in place,
+* ONE hipGraph per (call kind, step mode) holding the whole step -- latent broadcast + timestep
+  (tmix_step_prologue), the UNet launch chains, the fused step for all co-batched seeds: a timestep is one 32-byte
+  parameter upload and one graph replay.
 
-Out of scope here (SURVEY 8f "next" rows): the HF checkpoint/tokenizer/text-encoder loading of
-`Tweediemix.__init__`, the VAE decode at the end of `sample_loop`, and the segmentation side-car
-process; their inputs/outputs (prompt embeddings, masks) are constructor arguments instead.
+The constructor takes prompt embeddings, masks and weights as tensors; `tweediemix_amd/text.py` (tokenizer + text
+towers), `vae.py` (final / preview decode) and `masks.py` (side-car contract) produce them from the reference's inputs
+-- the CLI `fusion_generation/fusion_sampling.py` wires them together.  The segmentation process itself
+(GroundingDINO + SAM) stays an external command.
 """
 from __future__ import annotations
 
@@ -81,6 +86,7 @@ class Tweediemix:
         self.n_streams = int(n_streams)
         # optional VAE decoder: (config, state_dict) of tweediemix_amd.vae -- enables decode_latent / decoded outputs
         self.vae = vae
+        self.vae_scaling_factor = 0.13025       # SDXL VAE config value; the CLI overrides it from the checkpoint's vae/config.json
         self._vae_plans = {}
         # a call is split into chains only when each keeps >= 2 batch rows: the B = 2 CFG-pair calls run faster as ONE chain
         # with the one-workgroup-per-CU tilings (25.3 ms) than as two single-row chains (27.5 ms)
@@ -88,7 +94,7 @@ class Tweediemix:
         self.text_embeds = text_embeds
         self.text_embeds_single = text_embeds_single
         self.mask_provider = mask_provider
-        self.masks = None
+        self._mask_buf = None
         self.scheduler = Schedule(config.n_timesteps)
         self.skip = self.scheduler.skip
         self.final_alpha_cumprod = self.scheduler.final_alpha_cumprod
@@ -101,7 +107,17 @@ class Tweediemix:
         self.graphs = {}
         self.unet_calls = []          # (kind, B, t) trace, for tests / accounting
         self.preview_x0 = None
-        self._bufs = [torch.empty(self.n_seeds, 4, self.h, self.w, device=self.device, dtype=F32) for _ in range(3)]
+        S = self.n_seeds
+        # latent state of the running trajectories (updated in place by every step), its Tweedie estimate, a backup for
+        # the jumping look-ahead (fusion_sampling.py:431-447 does not move the trajectory), and the step parameters
+        self.x_state = torch.zeros(S, 4, self.h, self.w, device=self.device, dtype=F32)
+        self.x0_state = torch.zeros_like(self.x_state)
+        self._x_backup = torch.zeros_like(self.x_state)
+        self.step_params = torch.zeros(8, device=self.device, dtype=F32)      # {t, sa, s1, sa_next, s1_next, is_last, g, -}
+        self._hp = torch.zeros(8, dtype=F32)
+        if self.device.type == "cuda":
+            self._hp = self._hp.pin_memory()
+        self._mask_buf = None            # fixed-address copy of self.masks that the captured fusion step reads
 
     # ------------------------------------------------------------------ schedule
     def alpha(self, t):
@@ -146,25 +162,79 @@ class Tweediemix:
 
     def _unet(self, kind, x, t):
         """eps [n_seeds*rows,4,h,w] fp32 for the call kind's prompt rows; each seed's latent is broadcast over
-        its rows."""
+        its rows.  (UNet call alone, eager: used by tests and tools; the sampler itself runs `_run_step`.)"""
         p = self.plan(kind)
         S = self.n_seeds
         self.unet_calls.append((kind, p.B // S, int(t)))
         p.latent.view(S, p.B // S, *p.latent.shape[1:]).copy_(x.unsqueeze(1))
         p.t_dev.fill_(float(t))
-        if self.use_graphs:
-            g = self.graphs.get(kind)
-            if g is None:
-                p.run()                                   # warm-up (sets kernel attributes) outside capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    p.run()
-                self.graphs[kind] = g
-            g.replay()
-        else:
-            p.run()
+        p.run()
         return p.eps
+
+    # ------------------------------------------------------------------ one whole step = one graph
+    def _set_masks(self, masks):
+        """masks [K,1,h,w] (one seed) or [n_seeds,K,1,h,w]: kept at a fixed address, because captured steps read it."""
+        masks = masks.to(self.device, F32).contiguous()
+        if self._mask_buf is None or self._mask_buf.shape != masks.shape:
+            assert not any(k[1] == L.STEP_FUSION for k in self.graphs), "mask shape changed after the fusion step was captured"
+            self._mask_buf = torch.empty_like(masks)
+        self._mask_buf.copy_(masks)
+
+    @property
+    def masks(self):
+        return self._mask_buf
+
+    @masks.setter
+    def masks(self, m):
+        if m is None:
+            self._mask_buf = None
+        else:
+            self._set_masks(m)
+
+    def _enqueue_step(self, kind, mode):
+        """the launches of one denoising step on the current stream: prologue, UNet chains, fused step (in place)."""
+        p = self.plan(kind)
+        S = self.n_seeds
+        rows = p.B // S
+        n = 4 * self.h * self.w
+        lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(lib.tmix_step_prologue(self.x_state.data_ptr(), p.latent.data_ptr(), p.t_dev.data_ptr(),
+                                       self.step_params.data_ptr(), S, rows, n, st), "tmix_step_prologue")
+        p.run()
+        m = self._mask_buf if mode == L.STEP_FUSION else None
+        mss = 0 if (m is None or m.dim() == 4) else self.concept_num * self.h * self.w
+        L.check(lib.tmix_fused_tweedie_step_dev(self.x_state.data_ptr(), p.eps.data_ptr(), L.F32, None if m is None else m.data_ptr(),
+                                                mss, self.x_state.data_ptr(), self.x0_state.data_ptr(), self.concept_num, 4,
+                                                self.h * self.w, mode, rows, S, self.step_params.data_ptr(), st),
+                "tmix_fused_tweedie_step_dev")
+
+    def _run_step(self, kind, mode, t, at, at_next, is_last=False):
+        """x_state <- step(x_state) for every seed; x0_state <- the Tweedie estimate.  Host work per step: eight floats."""
+        p = self.plan(kind)
+        self.unet_calls.append((kind, p.B // self.n_seeds, int(t)))
+        sa, s1, san, s1n = ops.step_coeffs(at, at_next)
+        hp = self._hp
+        hp[0], hp[1], hp[2], hp[3], hp[4] = float(t), sa, s1, san, s1n
+        hp[5], hp[6] = (1.0 if is_last else 0.0), float(self.config.guidance_scale)
+        self.step_params.copy_(hp, non_blocking=True)
+        if mode == L.STEP_FUSION:
+            assert self._mask_buf is not None, "fusion step before the masks were acquired"
+        if not self.use_graphs:
+            self._enqueue_step(kind, mode)
+            return
+        g = self.graphs.get((kind, mode))
+        if g is None:
+            self._enqueue_step(kind, mode)                # warm-up outside capture (kernel attributes, lazy module load);
+            torch.cuda.synchronize()                      # it has already performed this step, so no replay now
+            g = torch.cuda.CUDAGraph()
+            keep = self.x_state.clone()
+            with torch.cuda.graph(g):
+                self._enqueue_step(kind, mode)
+            self.x_state.copy_(keep)                      # capture does not execute, but keep the state explicit
+            self.graphs[(kind, mode)] = g
+            return
+        g.replay()
 
     # ------------------------------------------------------------------ VAE
     def _decode(self, latent, inv_scale):
@@ -184,7 +254,7 @@ class Tweediemix:
     @torch.no_grad()
     def decode_final(self, latent):
         """fusion_sampling.py:496-524: x / vae.config.scaling_factor (0.13025) -> decoder -> (img/2+0.5).clamp(0,1)."""
-        return self._decode(latent, 1 / 0.13025)
+        return self._decode(latent, 1 / self.vae_scaling_factor)
 
     # ------------------------------------------------------------------ phases
     def init_fusion(self, t_cond, t_stop=None):
@@ -207,7 +277,7 @@ class Tweediemix:
         return t <= self.t_cond_cur
 
     def _step(self, x, eps, mode, at, at_next, is_last=False, out=None, out_x0=None):
-        """fused CFG/Tweedie/blend/DDIM for every seed (one launch per seed; eps rows of a seed are contiguous)."""
+        """fused CFG/Tweedie/blend/DDIM with host-side coefficients (scalar ABI form; tests and tools)."""
         S = self.n_seeds
         if out is None:
             out = torch.empty_like(x)
@@ -215,53 +285,56 @@ class Tweediemix:
         for sd in range(S):
             m = None
             if mode == L.STEP_FUSION:
-                m = self.masks if S == 1 else self.masks[sd]
+                m = self.masks if self.masks.dim() == 4 else self.masks[sd]
             ops.fused_tweedie_step(x[sd:sd + 1], eps[sd * rows:(sd + 1) * rows], m, mode, self.concept_num,
                                    self.config.guidance_scale, at, at_next, is_last, out_x=out[sd:sd + 1],
                                    out_x0=None if out_x0 is None else out_x0[sd:sd + 1])
         return out
 
-    @torch.no_grad()
-    def denoise_step(self, x, t):
-        """x [n_seeds,4,h,w] fp32 on the device, t python int (or 0-dim tensor). Returns the next latent(s)."""
+    def _denoise_inplace(self, t):
+        """one scheduler timestep on x_state (fusion_sampling.py:309-474)."""
         t = int(t)
         cfg = self.config
         next_t = t - self.skip
         at, at_next = self.alpha(t), self.alpha(next_t)
         last = t == 1
-        x0 = self._bufs[2]
         if self._in_fusion(t):
             kind = "fusion" if (t in self._window) else "fusion_base"
-            eps = self._unet(kind, x, t)
-            out = self._step(x, eps, L.STEP_FUSION, at, at_next, last, out_x0=x0)
+            self._run_step(kind, L.STEP_FUSION, t, at, at_next, last)
         elif t == self.start_t:
-            eps = self._unet("start", x, t)
             for _ in range(cfg.resampling_steps):
-                xd = self._step(x, eps, L.STEP_RESAMPLE, at, at_next, out=self._bufs[0])
-                eps_n = self._unet("plain", xd, next_t)
-                x = self._step(xd, eps_n, L.STEP_PLAIN, at_next, at, out=self._bufs[1])   # Tweedie at next_t, re-noise to t
-                eps = self._unet("start", x, t)
-            out = self._step(x, eps, L.STEP_PLAIN, at, at_next, last, out_x0=x0)
+                self._run_step("start", L.STEP_RESAMPLE, t, at, at_next)
+                self._run_step("plain", L.STEP_PLAIN, next_t, at_next, at)        # Tweedie at next_t, re-noise to t
+            self._run_step("start", L.STEP_PLAIN, t, at, at_next, last)
         else:
-            eps = self._unet("plain", x, t)
-            out = self._step(x, eps, L.STEP_PLAIN, at, at_next, last, out_x0=x0)
+            self._run_step("plain", L.STEP_PLAIN, t, at, at_next, last)
 
         if t == self.t_cond_prev:                       # fusion_sampling.py:431-469
-            xt, tt, x0j = out, next_t, x0
+            self._x_backup.copy_(self.x_state)          # the look-ahead does not move the trajectory
+            tt = next_t
             for _ in range(cfg.jumping_steps):
                 a_t = self.alpha(tt)
-                eps_j = self._unet("plain", xt, tt)
+                self._run_step("plain", L.STEP_PLAIN, tt, a_t, self.alpha(tt - 150))
                 tt = tt - 150
-                x0j = torch.empty_like(out)
-                xt = self._step(xt, eps_j, L.STEP_PLAIN, a_t, self.alpha(tt), out_x0=x0j)
-            self.preview_x0 = x0j.clone()
+            self.preview_x0 = (self.x0_state if cfg.jumping_steps else self._x_backup_x0()).clone()
+            self.x_state.copy_(self._x_backup)
             if self.n_seeds == 1:
-                self.masks = self.mask_provider(self.preview_x0).to(self.device, F32).contiguous()
-                assert self.masks.shape[0] == self.concept_num
+                m = self.mask_provider(self.preview_x0).to(self.device, F32).contiguous()
+                assert m.shape[0] == self.concept_num
             else:                                     # one mask set per seed: [n_seeds, K, 1, h, w]
-                self.masks = torch.stack([self.mask_provider(self.preview_x0[i:i + 1]).to(self.device, F32)
-                                          for i in range(self.n_seeds)]).contiguous()
-        return out
+                m = torch.stack([self.mask_provider(self.preview_x0[i:i + 1]).to(self.device, F32)
+                                 for i in range(self.n_seeds)]).contiguous()
+            self._set_masks(m)
+
+    def _x_backup_x0(self):
+        return self.x0_state            # jumping_steps == 0: the preview is the Tweedie estimate of the step just taken
+
+    @torch.no_grad()
+    def denoise_step(self, x, t):
+        """x [n_seeds,4,h,w] fp32 on the device, t python int (or 0-dim tensor). Returns the next latent(s)."""
+        self.x_state.copy_(x)
+        self._denoise_inplace(t)
+        return self.x_state.clone()
 
     def run_fusion(self, x=None, decode=False):
         cfg = self.config
@@ -271,13 +344,16 @@ class Tweediemix:
         else:
             self.init_fusion(t_cond)
         if x is None:      # drawn on the CPU like the reference (fusion_sampling.py:488): device-independent seeds
-            x = torch.randn(self.n_seeds, 4, self.h, self.w) * self.scheduler.init_noise_sigma
+            x = torch.randn(self.n_seeds, 4, self.h, self.w)
+        x = x * self.scheduler.init_noise_sigma          # :488 (1.0 for this scheduler), however x arrived
         return self.sample_loop(x.to(self.device, F32), decode=decode)
 
     @torch.no_grad()
     def sample_loop(self, x, decode=False):
         """runs every scheduler timestep; returns the final latent, or the decoded image [n,3,H,W] in [0,1] when
         decode=True and VAE weights were given (fusion_sampling.py:496-528)."""
+        self.x_state.copy_(x)
         for t in self.scheduler.timesteps:
-            x = self.denoise_step(x, t).clone()
+            self._denoise_inplace(t)
+        x = self.x_state.clone()
         return self.decode_final(x) if decode else x

@@ -151,9 +151,11 @@ class UNetWeights:
             """[1+K, N, Kin]: row 0 base, row 1+i = W + up_i @ down_i (utils_lora.py:65-79,113-119)."""
             rows = [base.to(dev, F32)]
             for csd in lora:
-                dn = csd[f"{key}.processor.to_{which}_lora.down.weight"].to(dev, F32)
-                up = csd[f"{key}.processor.to_{which}_lora.up.weight"].to(dev, F32)
-                rows.append(rows[0] + up @ dn)
+                kd, ku = f"{key}.processor.to_{which}_lora.down.weight", f"{key}.processor.to_{which}_lora.up.weight"
+                if kd in csd and ku in csd:
+                    rows.append(rows[0] + csd[ku].to(dev, F32) @ csd[kd].to(dev, F32))
+                else:       # the trainer's freeze_model='lora' checkpoints carry attn2 pairs only: a missing pair is a zero delta
+                    rows.append(rows[0])
             return torch.stack(rows)
 
         def fold(key, w, norm, bias=None):
@@ -170,8 +172,10 @@ class UNetWeights:
             t[a2 + ".out"] = bf(g(a2 + ".to_out.0.weight"))
             kv_rows = [torch.cat([g(a2 + ".to_k.weight"), g(a2 + ".to_v.weight")]).to(F32)]
             if custom is not None:                      # row 1+i: concept i's to_k / to_v (utils_custom.py:66-80)
-                for csd in custom:
-                    kv_rows.append(torch.cat([csd[a2 + ".to_k.weight"].to(dev, F32), csd[a2 + ".to_v.weight"].to(dev, F32)]))
+                for csd in custom:      # a block the checkpoint does not cover keeps the base projection (`if name in single_st['unet']`, fusion_sampling.py:206-209)
+                    ck = csd[a2 + ".to_k.weight"].to(dev, F32) if a2 + ".to_k.weight" in csd else kv_rows[0][:kv_rows[0].shape[0] // 2]
+                    cv = csd[a2 + ".to_v.weight"].to(dev, F32) if a2 + ".to_v.weight" in csd else kv_rows[0][kv_rows[0].shape[0] // 2:]
+                    kv_rows.append(torch.cat([ck, cv]))
             if lora is not None:
                 mk = merged(g(a2 + ".to_k.weight"), a2, "k")
                 mv = merged(g(a2 + ".to_v.weight"), a2, "v")
@@ -305,7 +309,7 @@ class UNetPlan:
 
     def __init__(self, W: UNetWeights, B: int, h: int, w: int, kv: KVCache, pooled: torch.Tensor,
                  time_ids: torch.Tensor, routed: bool = False, autotune: bool = True, row_sets=None,
-                 latent=None, eps=None, shared: bool = False):
+                 latent=None, eps=None, shared: bool = False, t_dev=None):
         self.W, self.cfg, self.B, self.h, self.w = W, W.cfg, B, h, w
         self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
@@ -321,12 +325,13 @@ class UNetPlan:
         self.flops = 0
         self.gemm_flops = 0
         self.launches = {"gemm": [], "conv": [], "attn": []}
+        self.op_meta = {}                   # index into self.ops -> (class, flops, shape key) of the instrumented launches
         cfg = self.cfg
         assert kv.B == B
         dev = self.dev
         # I/O buffers may be views into a larger batch owned by a PlanGroup (row-split execution on several streams)
         self.latent = latent if latent is not None else torch.zeros(B, cfg.in_channels, h, w, device=dev, dtype=F32)
-        self.t_dev = torch.zeros(B, device=dev, dtype=F32)
+        self.t_dev = t_dev if t_dev is not None else torch.zeros(B, device=dev, dtype=F32)
         self.eps = eps if eps is not None else torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
         assert self.latent.is_contiguous() and self.eps.is_contiguous() and self.latent.shape[0] == B
         # static conditioning: aug_emb = add_embedding(cat[pooled, sinusoid(time_ids)])  (depends on rows only)
@@ -426,6 +431,7 @@ class UNetPlan:
         W = self.W
         self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
                    W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu))
+        self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", self.B, HW, Cc))
         return out
 
     def _gemm(self, a, w, out, **kw):
@@ -443,6 +449,7 @@ class UNetPlan:
         self.gemm_flops += fl
         self.launches["gemm"].append((d, fl))
         self._tunable.append((len(self.ops) - 1, "gemm", d))
+        self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
         return out
 
     def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None, bias_images=1):
@@ -456,6 +463,7 @@ class UNetPlan:
         self.flops += fl
         self.launches["conv"].append((d, fl))
         self._tunable.append((len(self.ops) - 1, "conv", d))
+        self.op_meta[len(self.ops) - 1] = ("conv", fl, d)
         return out
 
     def _ln_stats(self, S, Cc):
@@ -478,6 +486,7 @@ class UNetPlan:
         fl = 4 * self.B * H * Sq * Skv * 64
         self.flops += fl
         self.launches["attn"].append((args, fl))
+        self.op_meta[len(self.ops) - 1] = ("attn", fl, ("attn", self.B, H, Sq, Skv))
         return out
 
     def _vt_buf(self, Cc, S):
@@ -655,6 +664,10 @@ class UNetPlan:
         self.ops = [(fn, tuple(a)) for fn, a in self.ops]
 
     # ------------------------------------------------------------------ execution
+    def issued_meta(self):
+        """(class, flops, key) of the instrumented launches (tmix_prof_begin) in the order run() issues them."""
+        return [self.op_meta[i] for i in range(len(self.ops)) if i in self.op_meta]
+
     def run(self, stream=None):
         """enqueue the whole forward on `stream` (default: torch's current stream). No sync, no alloc."""
         st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
@@ -743,6 +756,7 @@ class PlanGroup:
         cfg = W.cfg
         self.latent = torch.zeros(B, cfg.in_channels, h, w, device=dev, dtype=F32)
         self.eps = torch.zeros(B, cfg.out_channels, h, w, device=dev, dtype=F32)
+        self.t_dev = torch.zeros(B, device=dev, dtype=F32)      # one timestep vector; the chains hold views of their rows
         per = B // n_groups
         self.plans, self.streams = [], []
         for g in range(n_groups):
@@ -750,9 +764,8 @@ class PlanGroup:
             kv = KVCache(W, ehs[sl], list(wsel)[sl])
             self.plans.append(UNetPlan(W, per, h, w, kv, pooled[sl], time_ids[sl], routed=routed,
                                        row_sets=list(wsel)[sl] if routed else None,
-                                       latent=self.latent[sl], eps=self.eps[sl], shared=n_groups > 1))
+                                       latent=self.latent[sl], eps=self.eps[sl], shared=n_groups > 1, t_dev=self.t_dev[sl]))
             self.streams.append(torch.cuda.Stream(device=dev) if g > 0 else None)
-        self.t_dev = _FillAll([p.t_dev for p in self.plans])
         self.flops = sum(p.flops for p in self.plans)
         self.gemm_flops = sum(p.gemm_flops for p in self.plans)
         self.launches = {k: [x for p in self.plans for x in p.launches[k]] for k in ("gemm", "conv", "attn")}
@@ -760,6 +773,10 @@ class PlanGroup:
 
     def refine(self, **kw):
         return refine_group(self, **kw)
+
+    def issued_meta(self):
+        """run() enqueues the side-stream chains first, the main-stream chain last."""
+        return [m for p in self.plans[1:] + self.plans[:1] for m in p.issued_meta()]
 
     def run(self):
         main = torch.cuda.current_stream()
@@ -776,12 +793,3 @@ class PlanGroup:
         self.plans[0].run()
         for ev in joins:
             main.wait_event(ev)
-
-
-class _FillAll:
-    def __init__(self, ts):
-        self.ts = ts
-
-    def fill_(self, v):
-        for t in self.ts:
-            t.fill_(v)
