@@ -158,7 +158,7 @@ def insitu_profile(tw, reps=3):
     init = torch.zeros(n, 8, dtype=torch.int64)
     init[:, 0] = -1                                     # UINT64_MAX
     init = init.to(tw.device)
-    L.check(lib.tmix_prof_begin(slots.data_ptr(), n), "tmix_prof_begin")
+    L.check(lib.tmix_prof_begin(slots.data_ptr(), n, 0), "tmix_prof_begin")
     try:
         if tw.use_graphs:
             g = torch.cuda.CUDAGraph()
@@ -171,7 +171,7 @@ def insitu_profile(tw, reps=3):
         used = lib.tmix_prof_end()
     if run is None:                                     # eager mode: instrument every run
         def run():
-            lib.tmix_prof_begin(slots.data_ptr(), n)
+            lib.tmix_prof_begin(slots.data_ptr(), n, 0)
             tw._enqueue_step("fusion", L.STEP_FUSION)
             lib.tmix_prof_end()
     else:

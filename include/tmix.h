@@ -37,12 +37,14 @@ int tmix_check_device(void);
 
 /* In-situ launch timing (measurement only; no reference counterpart).  Between tmix_prof_begin and tmix_prof_end every
  * tmix_gemm_bf16 / tmix_conv3x3_nhwc / tmix_attn_fwd / tmix_groupnorm_nhwc launch issued by THIS host thread -- also while
- * it is being captured into a hipGraph -- takes the next 8-word slot of `slots` (device memory, capacity slots) and its
- * workgroups record into it, in ticks of the 100 MHz realtime clock: {min start, max end, sum(first operands landed -
- * start), sum(main loop done - start), sum(workgroup end - start), workgroups, -, -}.  The caller initialises every slot
- * to {UINT64_MAX, 0, 0, 0, 0, 0, 0, 0} before each measured run / replay.  tmix_prof_end returns the number of slots
- * handed out.  Launches issued outside such a bracket carry no instrumentation. */
-int tmix_prof_begin(uint64_t* slots, int capacity);
+ * it is being captured into a hipGraph -- takes the next 8-word slot of `slots` (device memory, capacity slots) and records
+ * into it, in ticks of the 100 MHz realtime clock: {start, end, sum(first operands landed - start), sum(main loop done -
+ * start), sum(workgroup end - start), workgroups, -, -}.  detail = 0: start is stored by the first workgroup, end by every
+ * workgroup (the last store wins), nothing else -- negligible cost, accurate to a store latency; detail = 1 (GEMM / conv /
+ * attention): exact min / max and the per-workgroup phase sums through atomics (this perturbs launches with thousands of
+ * workgroups).  The caller initialises every slot to {UINT64_MAX, 0, 0, 0, 0, 0, 0, 0} before each measured run / replay.
+ * tmix_prof_end returns the number of slots handed out.  Launches outside such a bracket carry no instrumentation. */
+int tmix_prof_begin(uint64_t* slots, int capacity, int detail);
 int tmix_prof_end(void);
 
 /* ---------------------------------------------------------------------------------------------

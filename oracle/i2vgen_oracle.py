@@ -145,7 +145,7 @@ def synthetic_state_dict(cfg: I2VConfig, seed=99, dtype=torch.float32):
 def _timesteps(t, dim):
     """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)."""
     half = dim // 2
-    freqs = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
     a = t.float()[:, None] * freqs[None]
     return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
 

@@ -7,7 +7,7 @@ This file restates the published SDXL-base architecture (UNet2DConditionModel co
 stabilityai/stable-diffusion-xl-base-1.0) with stock torch fp32 ops
 (F.conv2d, F.group_norm, F.layer_norm, F.scaled_dot_product_attention) and diffusers-compatible
 state-dict keys.  Anchors: (i) the parameter count of the full config is exactly 2,567,463,684
-(tests/test_unet_oracle.py), (ii) the attention hooks follow utils_custom.py:53-108 and
+(tests/test_host_cpu.py::test_parameter_inventories), (ii) the attention hooks follow utils_custom.py:53-108 and
 utils_lora.py:55-123, which ARE pinned by tests/golden/attention.npz.
 """
 from __future__ import annotations

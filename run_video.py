@@ -119,15 +119,20 @@ def main(argv=None):
     fps = torch.tensor([float(opt.target_fps)] * 2)
     fe, ctx, ilf = I.conditioning(Wt, fps, cond["image_latents"], cond["image_embeddings"], cond["prompt_embeds"])
     plan = (I.I2VPlanGroup if opt.streams == 2 else I.I2VPlan)(Wt, 2, Fr, h, w, fe, ctx, ilf, interp=opt.interp_ratio)
+    sched_json = os.path.join(opt.i2v_path, "scheduler", "scheduler_config.json") if opt.i2v_path else ""
+    sch_kw = {}
     if opt.alphas_cumprod:
         acp = np.load(opt.alphas_cumprod).astype(np.float32)
-    else:                                   # stand-in table: squaredcos_cap_v2 betas rescaled to zero terminal SNR
-        ab = np.cos((np.arange(1001) / 1000 + 0.008) / 1.008 * np.pi / 2) ** 2
-        betas = np.minimum(1 - ab[1:] / ab[:-1], 0.999)
-        s = np.sqrt(np.cumprod(1 - betas))
-        s = (s - s[-1]) * s[0] / (s[0] - s[-1])
-        acp = (s ** 2).astype(np.float32)
-    sch = V.VideoSchedule(acp, opt.num_inference_steps)
+    elif sched_json and os.path.exists(sched_json):      # the checkpoint's own DDIMScheduler settings (pipeline_i2vgen_xl.py:480)
+        import json
+        acp, sch_kw = V.alphas_from_scheduler_config(json.load(open(sched_json)))
+    else:                                   # stand-in: the published i2vgen-xl scheduler settings (squaredcos_cap_v2, zero terminal SNR)
+        if not opt.synthetic:
+            print("warning: no scheduler/scheduler_config.json under --i2v_path and no --alphas_cumprod: using the published "
+                  "i2vgen-xl settings (squaredcos_cap_v2, rescale_betas_zero_snr, steps_offset 1, set_alpha_to_one False)")
+        acp, sch_kw = V.alphas_from_scheduler_config(dict(beta_schedule="squaredcos_cap_v2", rescale_betas_zero_snr=True,
+                                                          steps_offset=1, set_alpha_to_one=False))
+    sch = V.VideoSchedule(acp, opt.num_inference_steps, **sch_kw)
     inj = V.FeatureInjector(sch.injection_schedule(opt.injection_timestep), opt.interp_ratio, clips=2, frames=Fr)
     x = torch.randn(1, 4, Fr, h, w, generator=gen).cuda()          # latents * init_noise_sigma (= 1 for DDIM)
     graphs = {}

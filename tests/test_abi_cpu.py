@@ -84,6 +84,6 @@ def test_argument_errors_are_reported_before_any_launch():
     assert l.tmix_step_prologue(fake, fake, fake, fake, 1, 4, 6, None) < 0            # n % 4
     assert l.tmix_fused_tweedie_step_dev(fake, fake, 0, None, 0, fake, None, 3, 4, 64, 0, 4, 1, fake, None) < 0   # FUSION without masks
     assert l.tmix_fused_tweedie_step_dev(fake, fake, 0, fake, 0, fake, None, 3, 4, 64, 0, 3, 1, fake, None) < 0   # too few eps rows
-    assert l.tmix_prof_begin(None, 4) < 0 and l.tmix_prof_end() == 0
+    assert l.tmix_prof_begin(None, 4, 0) < 0 and l.tmix_prof_end() == 0
     d = lib.GemmDesc()
     assert l.tmix_gemm_bf16(C.byref(d), None) < 0 and b"null" in l.tmix_last_error_string()

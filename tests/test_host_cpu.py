@@ -175,3 +175,45 @@ def test_tile_table_contexts():
     assert all(1 <= v <= L.TILE_COUNT for v in U._TUNE_CACHE.values())
     assert set(L.TILE_EXCLUSIVE) <= set(L.TILE_CANDIDATES)
 
+
+
+def test_video_alphas_follow_the_scheduler_config():
+    """run_video.py builds alphas_cumprod from the checkpoint's scheduler_config.json the way diffusers' DDIMScheduler does
+    (float32 tensors): scaled_linear reproduces the image sampler's table (tests/golden/schedule.npz, produced from the
+    reference's own scheduler arithmetic); zero-terminal-SNR rescaling ends at exactly 0; the keyword arguments follow the file."""
+    import os
+    from tweediemix_amd import video as V
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule.npz"))
+    acp, kw = V.alphas_from_scheduler_config(dict(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                                                  set_alpha_to_one=False))
+    key = [k for k in g.files if "alphas_cumprod" in k][0]
+    ref = np.asarray(g[key], np.float32)
+    ref = ref[1:] if len(ref) == 1001 else ref             # the image sampler's table has 1.0 prepended (fusion_sampling.py:218)
+    assert np.array_equal(acp, ref)
+    assert kw == dict(steps_offset=1, set_alpha_to_one=False)
+    acp0, kw0 = V.alphas_from_scheduler_config(dict(beta_schedule="squaredcos_cap_v2", rescale_betas_zero_snr=True))
+    assert acp0[-1] == 0.0 and 0.999 < acp0[0] < 1.0 and np.all(np.diff(acp0) <= 0) and kw0 == dict(steps_offset=0, set_alpha_to_one=True)
+    sch = V.VideoSchedule(acp0, 50, **kw0)
+    assert sch.final_alpha_cumprod == 1.0 and sch.timesteps[0] == 980 and sch.timesteps[-1] == 0
+
+
+def test_weights_tolerate_checkpoints_without_attn1_lora_or_custom_kv():
+    """the reference trainer's freeze_model='lora' checkpoints hold attn2 pairs only, and a Custom-Diffusion delta may not cover
+    every block (fusion_sampling.py:206-209 `if name in single_st['unet']`): a missing pair is a zero delta / the base K,V."""
+    from tweediemix_amd import unet as U, weights as Wt
+    cfg = U.TINY
+    sd = Wt.synthetic_state_dict(cfg, seed=3, device="cpu", dtype=torch.float32)
+    tb0 = U.attention_blocks(cfg)[0][0]
+    con = Wt.synthetic_concepts(cfg, "lora", 2, device="cpu")
+    con = [{k: v for k, v in c.items() if ".attn1." not in k} for c in con]
+    W = U.UNetWeights(cfg, sd, "cpu", ("lora", con))
+    a1 = tb0 + ".attn1"
+    rows = W[a1 + ".out_rows"]
+    assert rows.shape[0] == 3 and torch.equal(rows[1], rows[0]) and torch.equal(rows[2], rows[0])        # zero delta
+    a2 = tb0 + ".attn2"
+    assert not torch.equal(W[a2 + ".out_rows"][1], W[a2 + ".out_rows"][0])                               # attn2 pair applied
+    cc = Wt.synthetic_concepts(cfg, "custom", 2, device="cpu")
+    cc[1] = {k: v for k, v in cc[1].items() if not k.startswith(tb0)}
+    Wc = U.UNetWeights(cfg, sd, "cpu", ("custom", cc))
+    kv = Wc[a2 + ".kv_rows"]
+    assert kv.shape[0] == 3 and torch.equal(kv[2], kv[0]) and not torch.equal(kv[1], kv[0])

@@ -156,7 +156,7 @@ def test_prof_hook_times_launches_also_inside_a_graph(ops):
 
     work()
     torch.cuda.synchronize()
-    L.check(lib.tmix_prof_begin(slots.data_ptr(), 4), "tmix_prof_begin")
+    L.check(lib.tmix_prof_begin(slots.data_ptr(), 4, 0), "tmix_prof_begin")
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         work()
@@ -172,7 +172,7 @@ def test_prof_hook_times_launches_also_inside_a_graph(ops):
         s = slots.cpu().numpy().astype("uint64")
         for k in range(2):
             dur_us = (int(s[k, 1]) - int(s[k, 0])) * 0.01
-            assert 0.5 < dur_us < 5000.0 and s[k, 5] >= 1, (k, s[k])
+            assert 0.5 < dur_us < 5000.0, (k, s[k])
         assert int(s[1, 0]) >= int(s[0, 0])              # the norm starts after the GEMM started (same stream)
         assert (s[2:] == init.cpu().numpy().astype("uint64")[2:]).all()
 

@@ -148,7 +148,7 @@ int main(int argc, char** argv) {
                 std::vector<uint64_t> init(NL * 8, 0); for (int i = 0; i < NL; ++i) init[i * 8] = ~0ull;
                 CK(hipMemcpy(slots, init.data(), NL * 64, hipMemcpyHostToDevice));
                 std::vector<tmix_gemm_desc> ds; for (int s = 0; s < nset; ++s) ds.push_back(mk(s, cfg));
-                tmix_prof_begin(slots, NL);
+                tmix_prof_begin(slots, NL, 1);
                 for (int r = 0; r < NL; ++r) tmix_gemm_bf16(&ds[(r + 1) % ds.size()], st);
                 tmix_prof_end();
                 CK(hipStreamSynchronize(st));

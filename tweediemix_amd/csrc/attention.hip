@@ -37,7 +37,7 @@ struct AttnParams {
     bf16_t* O; int64_t ldo, strideO;
     int H, Sq, Skv, nq;
     float scale_log2e;
-    unsigned long long* prof;          // in-situ timing slot (common.h) or NULL
+    unsigned long long* prof; int prof_detail;   // in-situ timing slot (common.h) or NULL
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     const int fr = lane & 15, fg = lane >> 4;
     const bool prof_on = p.prof != nullptr && tid == 0;
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
-    if (prof_on) pt0 = prof_enter(p.prof);
+    if (prof_on) pt0 = prof_enter(p.prof, blockIdx.x == 0, p.prof_detail);
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = bid / p.nq, qt = bid - bh * p.nq;
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
             *(uint2*)(Ob + (int64_t)q * p.ldo + df * 16 + fg * 4) = v;
         }
     }
-    if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+    if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
 }
 
 }  // namespace
@@ -307,7 +307,7 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     p.O = (bf16_t*)O; p.ldo = ldo; p.strideO = strideO;
     p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
     p.scale_log2e = scale * 1.4426950408889634f;
-    p.prof = tmix_prof_take();
+    p.prof = tmix_prof_take(&p.prof_detail);
     const int64_t nwg = (int64_t)p.nq * B * H;
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
     attn_fwd_kernel<<<dim3((unsigned)nwg), 256, SMEM, (hipStream_t)stream>>>(p);

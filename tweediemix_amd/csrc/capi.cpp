@@ -11,17 +11,17 @@ void tmix_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static thread_local TmixProf g_prof = {nullptr, 0, 0};
+static thread_local TmixProf g_prof = {nullptr, 0, 0, 0};
 TmixProf& tmix_prof_state() { return g_prof; }
 
-extern "C" int tmix_prof_begin(uint64_t* slots, int capacity) {
+extern "C" int tmix_prof_begin(uint64_t* slots, int capacity, int detail) {
     if (!slots || capacity < 1 || (((uintptr_t)slots) & 7)) TMIX_FAIL(TMIX_EINVAL, "prof_begin: need an 8-byte aligned device buffer of capacity >= 1 slots");
-    g_prof.buf = (unsigned long long*)slots; g_prof.cap = capacity; g_prof.next = 0;
+    g_prof.buf = (unsigned long long*)slots; g_prof.cap = capacity; g_prof.next = 0; g_prof.detail = detail ? 1 : 0;
     return TMIX_OK;
 }
 extern "C" int tmix_prof_end(void) {
     const int used = g_prof.next;
-    g_prof.buf = nullptr; g_prof.cap = 0; g_prof.next = 0;
+    g_prof.buf = nullptr; g_prof.cap = 0; g_prof.next = 0; g_prof.detail = 0;
     return used;
 }
 

@@ -51,25 +51,34 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0
 // instrumented launch (GEMM, conv, attention, GroupNorm) takes the next 8-word slot of the caller's device buffer --
 // also when the launch is being captured into a hipGraph, so replays of that graph time the launches in the schedule the
 // product really runs (two concurrent chains, graph dependencies), which rocprofv3 serialises.  Slot layout, ticks of the
-// 100 MHz s_memrealtime clock: {min start, max end, sum(t1 - t0), sum(t2 - t0), sum(t3 - t0), workgroups, -, -} where per
-// workgroup t0 = entry, t1 = first operands landed, t2 = main loop done, t3 = epilogue stores issued.
-struct TmixProf { unsigned long long* buf; int cap, next; };
+// 100 MHz s_memrealtime clock: {start, end, sum(t1 - t0), sum(t2 - t0), sum(t3 - t0), workgroups, -, -}.
+// Plain mode costs a launch next to nothing: workgroup 0 (the first one dispatched) stores the start, EVERY workgroup
+// stores its end time with a write-through store and the last one to land wins (within a store latency of the true
+// maximum; read-modify-write atomics on one address from thousands of workgroups stretched 4096-workgroup launches by
+// 2x).  Detail mode (tools/gemm_lab) adds the per-workgroup phase sums with atomics: t0 = entry, t1 = first operands
+// landed, t2 = main loop done, t3 = epilogue stores issued; start / end become exact min / max.
+struct TmixProf { unsigned long long* buf; int cap, next, detail; };
 TmixProf& tmix_prof_state();
-static inline unsigned long long* tmix_prof_take() {
+static inline unsigned long long* tmix_prof_take(int* detail = nullptr) {
     TmixProf& st = tmix_prof_state();
+    if (detail) *detail = st.detail;
     if (!st.buf || st.next >= st.cap) return nullptr;
     return st.buf + 8 * (size_t)(st.next++);
 }
 __device__ __forceinline__ unsigned long long prof_now() { return __builtin_amdgcn_s_memrealtime(); }
-__device__ __forceinline__ unsigned long long prof_enter(unsigned long long* slot) {      // call from ONE thread per workgroup
+// call from ONE thread per workgroup; `first` = this is the workgroup dispatched first (linear block id 0)
+__device__ __forceinline__ unsigned long long prof_enter(unsigned long long* slot, bool first, int detail) {
     const unsigned long long t = prof_now();
-    atomicMin(slot, t);
+    if (detail) atomicMin(slot, t);
+    else if (first) __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return t;
 }
-__device__ __forceinline__ void prof_leave(unsigned long long* slot, unsigned long long t0, unsigned long long t1, unsigned long long t2) {
+__device__ __forceinline__ void prof_leave(unsigned long long* slot, int detail, unsigned long long t0, unsigned long long t1, unsigned long long t2) {
     const unsigned long long t3 = prof_now();
-    atomicMax(slot + 1, t3);
-    atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, t2 - t0); atomicAdd(slot + 4, t3 - t0); atomicAdd(slot + 5, 1ull);
+    if (detail) {
+        atomicMax(slot + 1, t3);
+        atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, t2 - t0); atomicAdd(slot + 4, t3 - t0); atomicAdd(slot + 5, 1ull);
+    } else __hip_atomic_store(slot + 1, t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids land on

@@ -46,7 +46,7 @@ struct Params {
     float ln_inv_c, ln_eps; int ln_parts;
     // convolution geometry (CONV only)
     int H, Wd, Cin, Ho, Wo, mode, ntaps;
-    unsigned long long* prof;         // in-situ timing slot (common.h) or NULL
+    unsigned long long* prof; int prof_detail;   // in-situ timing slot (common.h) or NULL
     int wide;                         // bit 0 / 1 / 2: the C / GEGLU / Ct stores may use the LDS-staged 16-byte form
 };
 
@@ -99,7 +99,7 @@ gemm_conv_kernel(const Params p) {
     const int wr = w / WN, wc = w - wr * WN;
     const bool prof_on = p.prof != nullptr && tid == 0;
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
-    if (prof_on) pt0 = prof_enter(p.prof);
+    if (prof_on) pt0 = prof_enter(p.prof, (blockIdx.x | blockIdx.y) == 0, p.prof_detail);
     const bool loader = LW && (w == NW);               // wave-uniform role
     const bool stager = LW ? loader : true;
     const int sw_id = LW ? 0 : w;                      // this wave's slot among the staging waves
@@ -582,7 +582,7 @@ gemm_conv_kernel(const Params p) {
                         }
                     }
                 }
-                if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+                if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
                 return;
             }
 #pragma unroll
@@ -613,7 +613,7 @@ gemm_conv_kernel(const Params p) {
                     }
             }
         }
-        if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
         return;
     }
 
@@ -661,7 +661,7 @@ gemm_conv_kernel(const Params p) {
                 if constexpr (R4 >= 2) chunk(i, C4 * 4, std::integral_constant<int, 2>{});
                 if constexpr (R4 & 1) chunk(i, FN - 1, std::integral_constant<int, 1>{});
             }
-            if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+            if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
             return;
         }
 #pragma unroll
@@ -688,7 +688,7 @@ gemm_conv_kernel(const Params p) {
                 }
             }
         }
-        if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
         return;
     }
     // LayerNorm producer side: {sum, sum of squares} of every row of this tile AS STORED (bf16-rounded), reduced over
@@ -829,7 +829,7 @@ gemm_conv_kernel(const Params p) {
                 sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
             }
         }
-        if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
         return;
     }
     float2* red = (float2*)smem;                                // [WN][BM]: the staging ring is free by now
@@ -895,7 +895,7 @@ gemm_conv_kernel(const Params p) {
             sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
         }
     }
-    if (prof_on) prof_leave(p.prof, pt0, pt1, pt2);
+    if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
 }
 
 // ------------------------------------------------------------------------------------------- launch
@@ -935,7 +935,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     p.group_m = BM >= 256 ? 4 : 8;
     if (BM >= 256 && BN >= 256) p.group_m = 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
-    p.prof = tmix_prof_take();
+    p.prof = tmix_prof_take(&p.prof_detail);
     kern<<<grid, (WM * WN + LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;

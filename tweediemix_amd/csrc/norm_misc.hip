@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
                                                        float* __restrict__ ws, int64_t HW, int groups, int chunks,
                                                        unsigned long long* prof) {
     __shared__ float s_sum[GN_MAX_C], s_sq[GN_MAX_C];
-    if (prof && threadIdx.x == 0) prof_enter(prof);            // in-situ timing (common.h): the norm's three launches share a slot
+    if (prof && threadIdx.x == 0) prof_enter(prof, (blockIdx.x | blockIdx.y) == 0, 0);   // in-situ timing (common.h): the norm's three launches share a slot
     const int C = C1 + C2, nvec = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int64_t ppc = (HW + chunks - 1) / chunks;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
             }
         }
     }
-    if (prof && threadIdx.x == 0) prof_leave(prof, pt0, pt0, pt0);
+    if (prof && threadIdx.x == 0) prof_leave(prof, 0, pt0, pt0, pt0);
 }
 
 // ------------------------------------------------------------------------------ LayerNorm

@@ -1,8 +1,8 @@
 """Host side of the video sampler's per-step path (BASELINE config #5): the denoising loop of
 video_gen/pipeline_i2vgen_xl.py:647-719 and the feature-injection schedule of video_gen/utils_attn.py:14-23,389-474, over
 the HIP kernels `tmix_vpred_step` and `tmix_frame_inject`.  The I2VGen-XL UNet itself (diffusers `I2VGenXLUNet`, not in
-/root/reference) is NOT rebuilt in this round: the loop takes the network as a callable, so the reference's own module (or
-a later native one) plugs in; everything the reference does around that call is here.
+/root/reference) is built natively in tweediemix_amd/i2vgen.py (I2VPlan / I2VPlanGroup); the loop here takes the network as a
+callable, so that plan (as run_video.py wires it) or any other module plugs in.
 
 Quirks kept: alpha(t) indexes the UN-shifted alphas_cumprod (unlike the image sampler) and falls back to
 final_alpha_cumprod below 0 (:480-482); skip = 1000 // n (:647); the injection schedule is the first int(n * ratio)
@@ -32,6 +32,37 @@ class VideoSchedule:
     def injection_schedule(self, ratio: float):
         k = int(self.n * ratio)
         return set(int(t) for t in self.timesteps[:k]) if k >= 0 else set()
+
+
+def alphas_from_scheduler_config(cfg: dict):
+    """alphas_cumprod (fp32 [num_train_timesteps]) and the VideoSchedule keyword arguments a diffusers DDIMScheduler built
+    from `scheduler/scheduler_config.json` would hold (what `pipe.scheduler.alphas_cumprod` is at pipeline_i2vgen_xl.py:480):
+    the beta schedule, `rescale_betas_zero_snr`, `steps_offset` and `set_alpha_to_one` follow the checkpoint, in the
+    float32 arithmetic diffusers uses (torch.linspace / cumprod / sqrt on float32 tensors)."""
+    import math
+    T = int(cfg.get("num_train_timesteps", 1000))
+    b0, b1 = float(cfg.get("beta_start", 0.0001)), float(cfg.get("beta_end", 0.02))
+    sched = cfg.get("beta_schedule", "linear")
+    if cfg.get("trained_betas") is not None:
+        betas = torch.tensor(cfg["trained_betas"], dtype=torch.float32)
+    elif sched == "linear":
+        betas = torch.linspace(b0, b1, T, dtype=torch.float32)
+    elif sched == "scaled_linear":
+        betas = torch.linspace(b0 ** 0.5, b1 ** 0.5, T, dtype=torch.float32) ** 2
+    elif sched == "squaredcos_cap_v2":                       # betas_for_alpha_bar: python floats, then one float32 tensor
+        ab = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        betas = torch.tensor([min(1 - ab((i + 1) / T) / ab(i / T), 0.999) for i in range(T)], dtype=torch.float32)
+    else:
+        raise ValueError(f"beta_schedule {sched!r} is not one of diffusers DDIMScheduler's")
+    if cfg.get("rescale_betas_zero_snr", False):             # rescale_zero_terminal_snr
+        abs_ = torch.cumprod(1.0 - betas, dim=0).sqrt()
+        a0, aT = abs_[0].clone(), abs_[-1].clone()
+        abs_ = (abs_ - aT) * (a0 / (a0 - aT))
+        bar = abs_ ** 2
+        alphas = torch.cat([bar[0:1], bar[1:] / bar[:-1]])
+        betas = 1 - alphas
+    acp = torch.cumprod(1.0 - betas, dim=0).numpy().astype(np.float32)
+    return acp, dict(steps_offset=int(cfg.get("steps_offset", 0)), set_alpha_to_one=bool(cfg.get("set_alpha_to_one", True)))
 
 
 def injection_active(t: int, schedule) -> bool:
