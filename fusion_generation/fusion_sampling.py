@@ -167,7 +167,7 @@ def main(argv=None):
     if opt.mask_paths:
         fg = opt.mask_paths.split('+')
     elif opt.random_masks or opt.synthetic:
-        fg = M.random_rectangle_masks(K, opt.resolution_h, opt.resolution_w, seed=opt.seed)
+        fg = None                                        # seeded rectangles, one set per trajectory seed (drawn when the sampler asks)
     else:   # the reference's file contract (:453-466): the side-car writes '<seg_concept>.jpg' under output_path
         fg = [os.path.join(opt.output_path, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
         sidecar = True
@@ -194,7 +194,16 @@ def main(argv=None):
         say(f"note: {K} concepts -> UNet batch {K + 1}: the reference's attention hooks only route concept weights when the batch is 4 "
             f"(utils_custom.py:62, utils_lora.py:63), so like the reference this run uses the BASE weights for every row; "
             f"--no_strict_reference routes them")
-    tw = S.Tweediemix(opt, W, te, ts, lambda x0: M.build_masks(fg, h, w, opt.device), concept_num=K, lora=LORA,
+    current = {"ids": [opt.seed], "turn": 0}             # the seeds of the batch being sampled; the sampler asks once per seed, in order
+
+    def provider(x0):
+        if fg is not None:
+            return M.build_masks(fg, h, w, opt.device)
+        sd_ = current["ids"][current["turn"] % len(current["ids"])]
+        current["turn"] += 1
+        return M.build_masks(M.random_rectangle_masks(K, opt.resolution_h, opt.resolution_w, seed=sd_), h, w, opt.device)
+
+    tw = S.Tweediemix(opt, W, te, ts, provider, concept_num=K, lora=LORA,
                       strict_reference=strict, use_graphs=not opt.no_graphs, n_seeds=per, n_streams=opt.streams, vae=vae)
     if vae_scaling:                                       # fusion_sampling.py:518 divides by vae.config.scaling_factor
         tw.vae_scaling_factor = float(vae_scaling)
@@ -208,6 +217,7 @@ def main(argv=None):
     for b0 in range(0, len(seeds), per):
         batch = seeds[b0:b0 + per]
         ids = (batch + batch * per)[:per]                # a ragged last batch is padded with repeats and trimmed below
+        current["ids"], current["turn"] = ids, 0
         lat_b = tw.run_fusion(torch.cat([noise_for_seed(sd_, h, w) for sd_ in ids]))
         lats.append(lat_b[:len(batch)])
         if vae is not None:                               # fusion_sampling.py:496-528

@@ -249,7 +249,7 @@ def forward(p, cfg: I2VConfig, sample, t, fps_emb, context, il_feat):
     p = {k: v.float() for k, v in p.items()}
     B, C, Fr, H, W = sample.shape
     ch, nb = cfg.block_out_channels, len(cfg.block_out_channels)
-    te = _timesteps(torch.full((B,), float(t)), ch[0])
+    te = _timesteps(torch.full((B,), float(t), device=sample.device), ch[0])
     emb = F.linear(F.silu(F.linear(te, p["time_embedding.linear_1.weight"], p["time_embedding.linear_1.bias"])),
                    p["time_embedding.linear_2.weight"], p["time_embedding.linear_2.bias"]) + fps_emb
     emb = emb.repeat_interleave(Fr, dim=0)

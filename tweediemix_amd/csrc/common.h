@@ -52,10 +52,10 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0
 // also when the launch is being captured into a hipGraph, so replays of that graph time the launches in the schedule the
 // product really runs (two concurrent chains, graph dependencies), which rocprofv3 serialises.  Slot layout, ticks of the
 // 100 MHz s_memrealtime clock: {start, end, sum(t1 - t0), sum(t2 - t0), sum(t3 - t0), workgroups, -, -}.
-// Plain mode costs a launch next to nothing: workgroup 0 (the first one dispatched) stores the start, EVERY workgroup
-// stores its end time with a write-through store and the last one to land wins (within a store latency of the true
-// maximum; read-modify-write atomics on one address from thousands of workgroups stretched 4096-workgroup launches by
-// 2x).  Detail mode (tools/gemm_lab) adds the per-workgroup phase sums with atomics: t0 = entry, t1 = first operands
+// Plain mode costs a launch next to nothing: workgroup 0 (the first one dispatched) stores the start, the LAST 32
+// workgroups of the grid (dispatch is in order, so the last finisher is among them) store their end time with a
+// write-through store and the last one to land wins (within a store latency of the true maximum; read-modify-write
+// atomics -- or even plain stores -- on one address from thousands of workgroups stretched 4096-workgroup launches).  Detail mode (tools/gemm_lab) adds the per-workgroup phase sums with atomics: t0 = entry, t1 = first operands
 // landed, t2 = main loop done, t3 = epilogue stores issued; start / end become exact min / max.
 struct TmixProf { unsigned long long* buf; int cap, next, detail; };
 TmixProf& tmix_prof_state();
@@ -74,11 +74,14 @@ __device__ __forceinline__ unsigned long long prof_enter(unsigned long long* slo
     return t;
 }
 __device__ __forceinline__ void prof_leave(unsigned long long* slot, int detail, unsigned long long t0, unsigned long long t1, unsigned long long t2) {
-    const unsigned long long t3 = prof_now();
     if (detail) {
+        const unsigned long long t3 = prof_now();
         atomicMax(slot + 1, t3);
         atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, t2 - t0); atomicAdd(slot + 4, t3 - t0); atomicAdd(slot + 5, 1ull);
-    } else __hip_atomic_store(slot + 1, t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y * gridDim.z;
+        if (lin + 32 >= total) __hip_atomic_store(slot + 1, prof_now(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids land on

@@ -114,9 +114,13 @@ class Tweediemix:
         self.x0_state = torch.zeros_like(self.x_state)
         self._x_backup = torch.zeros_like(self.x_state)
         self.step_params = torch.zeros(8, device=self.device, dtype=F32)      # {t, sa, s1, sa_next, s1_next, is_last, g, -}
-        self._hp = torch.zeros(8, dtype=F32)
+        # pinned staging ring for the asynchronous parameter upload: a slot is rewritten only after the copy that read it
+        # has completed (the host runs ahead of the device by whole steps)
+        self._hp = torch.zeros(64, 8, dtype=F32)
         if self.device.type == "cuda":
             self._hp = self._hp.pin_memory()
+        self._hp_ev = [None] * self._hp.shape[0]
+        self._hp_i = 0
         self._mask_buf = None            # fixed-address copy of self.masks that the captured fusion step reads
 
     # ------------------------------------------------------------------ schedule
@@ -211,15 +215,34 @@ class Tweediemix:
 
     def _run_step(self, kind, mode, t, at, at_next, is_last=False):
         """x_state <- step(x_state) for every seed; x0_state <- the Tweedie estimate.  Host work per step: eight floats."""
-        p = self.plan(kind)
-        self.unet_calls.append((kind, p.B // self.n_seeds, int(t)))
+        if "_unet" not in vars(self):
+            self.unet_calls.append((kind, self.plan(kind).B // self.n_seeds, int(t)))
         sa, s1, san, s1n = ops.step_coeffs(at, at_next)
-        hp = self._hp
+        i = self._hp_i
+        self._hp_i = (i + 1) % self._hp.shape[0]
+        if self._hp_ev[i] is not None:
+            self._hp_ev[i].synchronize()
+        hp = self._hp[i]
         hp[0], hp[1], hp[2], hp[3], hp[4] = float(t), sa, s1, san, s1n
         hp[5], hp[6] = (1.0 if is_last else 0.0), float(self.config.guidance_scale)
         self.step_params.copy_(hp, non_blocking=True)
+        if self.device.type == "cuda":
+            self._hp_ev[i] = torch.cuda.Event()
+            self._hp_ev[i].record()
         if mode == L.STEP_FUSION:
             assert self._mask_buf is not None, "fusion step before the masks were acquired"
+        if "_unet" in vars(self):
+            # a stand-in UNet was attached to this instance (tests replay recorded eps; a caller may plug the reference's own
+            # module in): the same fused step, eagerly, on whatever eps dtype the stand-in returns
+            eps = self._unet(kind, self.x_state, t).contiguous()
+            S = self.n_seeds
+            m = self._mask_buf if mode == L.STEP_FUSION else None
+            mss = 0 if (m is None or m.dim() == 4) else self.concept_num * self.h * self.w
+            L.check(L.load().tmix_fused_tweedie_step_dev(
+                self.x_state.data_ptr(), eps.data_ptr(), ops._EPS_DT[eps.dtype], None if m is None else m.data_ptr(), mss,
+                self.x_state.data_ptr(), self.x0_state.data_ptr(), self.concept_num, 4, self.h * self.w, mode, eps.shape[0] // S, S,
+                self.step_params.data_ptr(), torch.cuda.current_stream().cuda_stream), "tmix_fused_tweedie_step_dev")
+            return
         if not self.use_graphs:
             self._enqueue_step(kind, mode)
             return
