@@ -38,6 +38,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kind", default="both", choices=["both", "lora", "custom"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the FF / attn1-QKV projections run on e4m3 operands (tmix_gemm_fp8); a separate line, never the headline")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--tiny", action="store_true", help="tiny UNet (debug only; not a valid bench line)")
     ap.add_argument("--no-graphs", action="store_true")
@@ -55,7 +57,7 @@ def parse(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ sampler construction
-def build_sampler(args, kind, device, seed):
+def build_sampler(args, kind, device, seed, fp8=None):
     from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
     cfg = U.TINY if args.tiny else U.SDXL
     K = 3
@@ -80,7 +82,7 @@ def build_sampler(args, kind, device, seed):
         return mask_set((turn[0] - 1) % S_)
 
     tw = S.Tweediemix(conf, W, te, ts, provider, concept_num=K, lora=(kind == "lora"), use_graphs=not args.no_graphs,
-                      n_seeds=S_, n_streams=args.streams)
+                      n_seeds=S_, n_streams=args.streams, fp8=(getattr(args, "dtype", "bf16") == "fp8") if fp8 is None else fp8)
     tw.min_rows_per_stream = int(os.environ.get("TMIX_MIN_ROWS_PER_STREAM", str(tw.min_rows_per_stream)))
     tw.init_fusion(int(50 * 0.2), int(50 * 0.8)) if kind == "lora" else tw.init_fusion(int(50 * 0.2))
     tw.masks = mask_set(0) if S_ == 1 else torch.stack([mask_set(i) for i in range(S_)]).contiguous()
@@ -140,8 +142,9 @@ def parity_check(tw, args, parts, kind, device):
     want = ref.x_state
     rel = float((got - want).norm() / want.norm())
     del ref
-    assert rel < 2e-2, f"timed path differs from the eager single-chain run: rel L2 {rel}"
-    return {"vs": "eager single-chain run of the same step (no graph, one stream)", "rel_l2": rel, "tol": 2e-2}
+    tol = 1e-1 if tw.fp8 else 2e-2
+    assert rel < tol, f"timed path differs from the eager single-chain run: rel L2 {rel}"
+    return {"vs": "eager single-chain bf16 run of the same step (no graph, one stream)", "rel_l2": rel, "tol": tol}
 
 
 # ------------------------------------------------------------------------------------------------ in-situ roofline
@@ -441,6 +444,15 @@ def main(argv=None):
                            "ms_per_step": 1e3 * dt2 / (args.steps * S_), "parity_check": parity_check(tw2, args, _parts2, "custom", device)}
         del tw2
         torch.cuda.empty_cache()
+        if args.dtype == "bf16" and not args.tiny:
+            tw3, _parts3 = build_sampler(args, primary, device, seed=rank, fp8=True)
+            dt3, _ = timed_fusion_steps(tw3, args, world, device, x)
+            other["fp8"] = {"workload": f"{primary} deltas; attn1 q/k/v and the two FF projections of every transformer block on e4m3 operands with "
+                                        "per-row power-of-two scales (tmix_gemm_fp8), one quantiser launch per GEMM; everything else bf16",
+                            "dtype": "fp8", "value": S_ * args.steps / dt3, "unit": "steps/s", "ms_per_step": 1e3 * dt3 / (args.steps * S_),
+                            "parity_check": parity_check(tw3, args, _parts3, primary, device)}
+            del tw3
+            torch.cuda.empty_cache()
     else:
         alg = gemm_alg_bytes(plan)
         flops_step = plan.flops
@@ -450,7 +462,7 @@ def main(argv=None):
         line = {
             "metric": METRIC, "value": world * S_ * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / (args.steps * S_), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SDXL-base UNet shapes, {args.res}x{args.res}, K=3 concepts ({primary} deltas"
                                    + (", --t_stop 0.8 window" if primary == "lora" else "") + "), "
                                    f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel, one hipGraph per step"

@@ -145,6 +145,18 @@ typedef struct {
     int32_t ln_parts, reserved0;                      /* partials per row in ln_stats, 1..16 */
 } tmix_gemm_desc;
 int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
+/* The same GEMM on OCP fp8 (e4m3) operands -- the reference's precision bar is fp16 autocast (fusion_sampling.py:492); this is
+ * the optional lower-precision path for the FF / QKV projections (`--dtype fp8`), never the default.  A and W hold e4m3 BYTES
+ * (lda / ldw / strides in elements = bytes, multiples of 16; K %% 64 == 0) and every A row and W row carries one power-of-two
+ * scale, an E8M0 exponent byte: A[m][k] = a8[m][k] * 2^(scale_a[m] - 127).  scale_a is [batch][M], scale_w [N] (or [batch][N]
+ * when strideW != 0).  v_mfma_scale_f32_32x32x64_f8f6f4 applies both scales in hardware (per-row instead of the MX format's
+ * per-32 blocks, so a lane keeps its scales for the whole K loop); accumulation and every epilogue of tmix_gemm_bf16 (bias,
+ * fused LayerNorm on A, GEGLU, residual, transposed V, row statistics) are unchanged.  tile_cfg: TMIX_TILE_AUTO,
+ * TMIX_TILE_256x256_PH or TMIX_TILE_256x128_PH. */
+int tmix_gemm_fp8(const tmix_gemm_desc* d, const uint8_t* scale_a, const uint8_t* scale_w, void* stream);
+/* Row quantiser for tmix_gemm_fp8: X bf16 [rows][ld] -> Q e4m3 [rows][ldq] and scale_e8m0[r] = the smallest exponent that brings
+ * max|X[r]| under 448 (K %% 8 == 0, K <= 8192).  Used on activations before each fp8 GEMM and once on the weights. */
+int tmix_quantize_fp8_rows(const void* X, int64_t ld, void* Q, int64_t ldq, uint8_t* scale_e8m0, int64_t rows, int K, void* stream);
 /* workgroup tile of a TMIX_TILE_* id (bm x bn), and the number of row-statistics partials a GEMM of width N writes with it */
 int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn);
 int tmix_gemm_stats_parts(int N, int tile_cfg);

@@ -468,3 +468,68 @@ def test_gemm_transposed_region_on_a_128_boundary(ops, cfg):
     close(qk, ref[:, :, :2 * Cc], rtol=2 ** -6, atol_frac=4e-3)
     close(vt, ref[:, :, 2 * Cc:].transpose(1, 2), rtol=2 ** -6, atol_frac=4e-3)
     assert float(guard[:, S:].float().min()) == 7.0 and float(guard[:, S:].float().max()) == 7.0
+
+
+# --------------------------------------------------------------------------- fp8 (e4m3, per-row E8M0 scales)
+@pytest.mark.parametrize("rows,K", [(37, 64), (1024, 1280), (130, 5120)])
+def test_fp8_row_quantizer_matches_torch_float8(ops, rows, K):
+    """tmix_quantize_fp8_rows: the scale is the smallest power of two that brings the row's largest magnitude under 448, the
+    bytes are round-to-nearest-even OCP e4m3 -- bit-equal to torch's float8_e4m3fn conversion of the scaled row."""
+    x = rnd(rows, K, seed=rows, scale=3.0)
+    x[1] = 0                                              # an all-zero row keeps scale 1
+    x[2, 5] = 1000.0                                      # an outlier sets its row's scale
+    q, s = ops.quantize_fp8_rows(x)
+    torch.cuda.synchronize()
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)).float(), torch.zeros_like(amax))
+    assert torch.equal(s.float() - 127.0, e), (s[:4], e[:4])
+    ref = (xf * torch.exp2(-e).unsqueeze(1)).to(torch.float8_e4m3fn).view(torch.uint8)
+    same = (q == ref) | ((q & 0x7f) == 0) & ((ref & 0x7f) == 0)        # +0 / -0 both fine
+    assert same.all(), int((~same).sum())
+    back = ops.dequantize_fp8_rows(q, s)
+    assert float((back - xf).abs().max() / xf.abs().max()) < 2 ** -3   # 3 mantissa bits
+
+
+@pytest.mark.parametrize("tile", [0, 16, 17])
+@pytest.mark.parametrize("M,N,K,kw", [(512, 512, 256, {}), (1024, 1280, 1280, {"bias": True, "residual": True}),
+                                      (300, 264, 128, {"bias": True}), (2048, 2560, 1280, {"geglu": True}),
+                                      (1024, 3840, 1280, {"trans": True, "batch": 2})])
+def test_gemm_fp8_equals_fp32_product_of_the_dequantized_operands(ops, tile, M, N, K, kw):
+    """tmix_gemm_fp8 (v_mfma_scale_f32_32x32x64_f8f6f4, per-row scales applied by the instruction) against the fp32 matmul of
+    exactly the values it reads: products of e4m3 values are exact in fp32, so only the accumulation order and the final bf16
+    rounding separate the two.  Also reports what the quantisation itself costs against the unquantised bf16 operands."""
+    batch = kw.get("batch", 1)
+    a = rnd(batch, M, K, seed=1) if batch > 1 else rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    a8, sa = ops.quantize_fp8_rows(a)
+    w8, sw = ops.quantize_fp8_rows(w)
+    ad, wd = ops.dequantize_fp8_rows(a8, sa), ops.dequantize_fp8_rows(w8, sw)
+    bias = torch.randn(N, device="cuda") if (kw.get("bias") or kw.get("geglu")) else None
+    res = rnd(M, N, seed=3) if kw.get("residual") else None
+    ref = ad @ wd.t() + (bias if bias is not None else 0)
+    exact = a.float() @ w.float().t() + (bias if bias is not None else 0)
+    if kw.get("geglu"):
+        from tweediemix_amd.weights import interleave_geglu
+        wi, bi = interleave_geglu(w.float(), bias)
+        w8, sw = ops.quantize_fp8_rows(wi.to(BF).contiguous())
+        wd = ops.dequantize_fp8_rows(w8, sw)
+        full = ad @ wd.t() + bi
+        # un-interleave: groups of 32 rows = 16 value rows then 16 gate rows
+        v = full.view(M, N // 32, 2, 16)
+        ref = (v[:, :, 0] * F.gelu(v[:, :, 1])).reshape(M, N // 2)
+        out = ops.gemm_fp8(a8, sa, w8, sw, bias=bi.contiguous(), geglu=True, tile_cfg=tile)
+        close(out, ref, rtol=2 ** -6)
+        return
+    if kw.get("trans"):
+        ntb = N // 3 * 2
+        vt = torch.zeros(batch, N - ntb, M, device="cuda", dtype=BF)
+        out = ops.gemm_fp8(a8, sa, w8, sw, bias=bias, out_t=vt, n_trans_begin=ntb, tile_cfg=tile)
+        close(out, ref[..., :ntb])
+        close(vt, ref[..., ntb:].transpose(1, 2))
+        return
+    out = ops.gemm_fp8(a8, sa, w8, sw, bias=bias, residual=res, tile_cfg=tile)
+    close(out, ref + (res.float() if res is not None else 0))
+    err = float((out.float() - (exact + (res.float() if res is not None else 0))).norm() / exact.norm())
+    print(f"fp8 GEMM {M}x{N}x{K}: rel-L2 vs the unquantised bf16 product = {err:.3e}")
+    assert err < 6e-2

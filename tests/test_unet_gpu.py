@@ -243,3 +243,44 @@ def test_headline_size_plan_group_graph_vs_fp32_oracle(sdxl_weights, kind, hw):
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
     print(f"SDXL {kind} {res}^2 B=4, two chains, graph replay: rel_l2={r:.4g} max_rel={m:.4g}")
     assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)
+
+
+def test_fp8_projections_tiny_unet_vs_oracle():
+    """--dtype fp8 on the tiny UNet: attn1 q/k/v and both FF projections on e4m3 operands (tmix_gemm_fp8 behind one quantiser
+    launch each), everything else bf16 -- against the fp32 oracle.  States the cost: bf16 path ~4e-3, fp8 within 6e-2."""
+    from tweediemix_amd import unet as U
+    orc, plan, x, ehs, pooled, tid = make("custom", 4, 16, 16, True)
+    ref = orc.forward(x, 500, ehs, pooled, tid, routed=True)
+    base = rel_l2(plan(x.cuda(), 500).clone(), ref)
+    p8 = U.UNetPlan(plan.W, 4, 16, 16, plan.kv, pooled, tid, routed=True, fp8=True)
+    got = p8(x.cuda(), 500).clone()
+    r = rel_l2(got, ref)
+    print(f"tiny UNet rel-L2 vs fp32 oracle: bf16 {base:.3e}, fp8 projections {r:.3e}")
+    assert torch.isfinite(got).all() and base <= 2e-2 and r <= 6e-2, (base, r)
+
+
+@pytest.mark.parametrize("kind", ["custom", "lora"])
+def test_fp8_projections_full_size_sdxl_vs_oracle(sdxl_weights, kind):
+    """the same at the real SDXL shapes (512 x 512, B = 4 routed rows, two chains): whole-UNet rel-L2 of the fp8 path vs the
+    fp32 oracle, measured and bounded (<= 8e-2; the bf16 path is bounded at 2e-2 by the tests above)."""
+    from oracle import unet_oracle as UO
+    from tweediemix_amd import unet as U, weights as Wt
+    cfg, sd, hw = U.SDXL, sdxl_weights, 64
+    con = Wt.synthetic_concepts(cfg, kind, 3, device="cuda")
+    g = torch.Generator().manual_seed(6)
+    B, res = 4, hw * 8
+    ehs = torch.randn(B, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
+    tid = torch.tensor([[float(res), res, 0, 0, res, res]] * B)
+    x = torch.randn(1, 4, hw, hw, generator=g).repeat(B, 1, 1, 1).cuda()
+    W = U.UNetWeights(cfg, sd, "cuda", (kind, con))
+    grp = U.PlanGroup(W, hw, hw, ehs, [0, 1, 2, 3], pooled, tid, True, 2, fp8=True)
+    grp.latent.copy_(x)
+    grp.t_dev.fill_(601.0)
+    grp.run()
+    torch.cuda.synchronize()
+    eps = grp.eps.clone()
+    ref = UO.UNetOracle(UO.SDXL, sd, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    r = rel_l2(eps, ref)
+    print(f"SDXL {kind} {res}^2 B=4 fp8 projections: rel_l2={r:.4g}")
+    assert torch.isfinite(eps).all() and r <= 8e-2, r

@@ -1,6 +1,7 @@
 // gemm_lab -- standalone (no Python, no torch) timing + correctness harness for tmix_gemm_bf16 through the C ABI.
 //   lab [check|time] M,N,K[,batch[,flags]] ... -- cfgs=1,2,16  reps=30
-// flags (letters): b bias, r residual, g GEGLU, s row_stats_out, t transposed tail (last third of N, batch must divide M)
+// flags (letters): b bias, r residual, g GEGLU, s row_stats_out, t transposed tail (last third of N, batch must divide M),
+//                  f fp8 operands (quantised once by tmix_quantize_fp8_rows, then tmix_gemm_fp8 is timed)
 // "hot"  : the same operands every launch (everything L2 / Infinity-Cache resident after the first pass)
 // "cold" : the launch cycles through enough operand sets to exceed the 256 MiB Infinity Cache (weights and activations cold)
 // Dev tool only: product code never links this.
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
     for (const Shape& sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K, B = sh.batch;
         const bool fb = sh.flags.find('b') != std::string::npos, fr = sh.flags.find('r') != std::string::npos, fg = sh.flags.find('g') != std::string::npos;
-        const bool fs = sh.flags.find('s') != std::string::npos, ft = sh.flags.find('t') != std::string::npos;
+        const bool fs = sh.flags.find('s') != std::string::npos, ft = sh.flags.find('t') != std::string::npos, f8 = sh.flags.find('f') != std::string::npos;
         const int Nout = fg ? N / 2 : N;
         const size_t szA = (size_t)B * M * K, szW = (size_t)N * K, szC = (size_t)B * M * Nout;
         const size_t set_bytes = 2 * (szA + szW + szC + (fr ? szC : 0));
@@ -80,6 +81,12 @@ int main(int argc, char** argv) {
             fill_bf16<<<1024, 256, 0, st>>>(Ws[s], szW, 91 + s, 1.0f / sqrtf((float)K) * 1.7f * dscale);
             fill_bf16<<<1024, 256, 0, st>>>(Rs[s], szC, 55 + s, 1.0f);
         }
+        std::vector<uint8_t*> A8(nset, nullptr), W8(nset, nullptr), SA(nset, nullptr), SW(nset, nullptr);
+        if (f8) for (int s = 0; s < nset; ++s) {
+            CK(hipMalloc(&A8[s], szA)); CK(hipMalloc(&W8[s], szW)); CK(hipMalloc(&SA[s], (size_t)B * M)); CK(hipMalloc(&SW[s], N));
+            if (tmix_quantize_fp8_rows(As[s], K, A8[s], K, SA[s], (int64_t)B * M, K, st) || tmix_quantize_fp8_rows(Ws[s], K, W8[s], K, SW[s], N, K, st)) {
+                fprintf(stderr, "quantize: %s\n", tmix_last_error_string()); return 2; }
+        }
         float* bias; CK(hipMalloc(&bias, N * 4)); fill_f32<<<64, 256, 0, st>>>(bias, N, 5, 0.5f);
         float* stats; CK(hipMalloc(&stats, (size_t)16 * B * M * 2 * 4));
         uint16_t* Ct = nullptr; const int ldct = (M + 7) / 8 * 8; const int ntb = ft ? (N / 3) * 2 : -1;
@@ -87,8 +94,8 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         auto mk = [&](int set, int cfg) {
             tmix_gemm_desc d; memset(&d, 0, sizeof d);
-            d.A = As[set]; d.lda = K; d.strideA = B > 1 ? (int64_t)M * K : 0;
-            d.W = Ws[set]; d.ldw = K; d.strideW = 0;
+            d.A = f8 ? (void*)A8[set] : (void*)As[set]; d.lda = K; d.strideA = B > 1 ? (int64_t)M * K : 0;
+            d.W = f8 ? (void*)W8[set] : (void*)Ws[set]; d.ldw = K; d.strideW = 0;
             d.C = Cs[set]; d.ldc = Nout; d.strideC = B > 1 ? (int64_t)M * Nout : 0;
             if (fb || fg) d.bias = bias;
             if (fr) { d.residual = Rs[set]; d.ldr = Nout; d.strideR = B > 1 ? (int64_t)M * Nout : 0; }
@@ -97,8 +104,9 @@ int main(int argc, char** argv) {
             if (fs) { d.row_stats_out = stats; d.strideStatsOut = 2 * M; d.ldStatsOut = (int64_t)B * M; }
             return d;
         };
+        auto run = [&](tmix_gemm_desc* d, int set) { return f8 ? tmix_gemm_fp8(d, SA[set], SW[set], st) : tmix_gemm_bf16(d, st); };
         std::vector<float> ref;
-        if (check && !fg && !ft) {
+        if (check && !fg && !ft && !f8) {
             float* Cr; CK(hipMalloc(&Cr, (size_t)B * M * N * 4));
             for (int b = 0; b < B; ++b)
                 ref_gemm<<<dim3((N + 255) / 256, M), 256, 0, st>>>(As[0] + (size_t)b * M * K, Ws[0], Cr + (size_t)b * M * N, M, N, K);
@@ -109,7 +117,7 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * B * M * N * K;
         for (int cfg : cfgs) {
             tmix_gemm_desc d0 = mk(0, cfg);
-            int rc = tmix_gemm_bf16(&d0, st);
+            int rc = run(&d0, 0);
             if (rc) { printf("  cfg %2d: rc %d (%s)\n", cfg, rc, tmix_last_error_string()); continue; }
             CK(hipStreamSynchronize(st));
             std::string verdict;
@@ -132,11 +140,11 @@ int main(int argc, char** argv) {
             for (int mode = 0; mode < 2; ++mode) {
                 if ((mode == 0 && !hot) || (mode == 1 && (!cold || nset < 2))) continue;
                 std::vector<tmix_gemm_desc> ds; for (int s = 0; s < (mode ? nset : 1); ++s) ds.push_back(mk(s, cfg));
-                for (int w = 0; w < 3; ++w) tmix_gemm_bf16(&ds[w % ds.size()], st);
+                for (int w = 0; w < 3; ++w) run(&ds[w % ds.size()], w % (int)ds.size());
                 double best = 1e30;
                 for (int round = 0; round < 3; ++round) {
                     CK(hipEventRecord(e0, st));
-                    for (int r = 0; r < reps; ++r) tmix_gemm_bf16(&ds[r % ds.size()], st);
+                    for (int r = 0; r < reps; ++r) run(&ds[r % ds.size()], r % (int)ds.size());
                     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, (double)ms * 1e3 / reps);
                 }
@@ -149,7 +157,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpy(slots, init.data(), NL * 64, hipMemcpyHostToDevice));
                 std::vector<tmix_gemm_desc> ds; for (int s = 0; s < nset; ++s) ds.push_back(mk(s, cfg));
                 tmix_prof_begin(slots, NL, 1);
-                for (int r = 0; r < NL; ++r) tmix_gemm_bf16(&ds[(r + 1) % ds.size()], st);
+                for (int r = 0; r < NL; ++r) run(&ds[(r + 1) % ds.size()], (r + 1) % (int)ds.size());
                 tmix_prof_end();
                 CK(hipStreamSynchronize(st));
                 std::vector<uint64_t> got(NL * 8); CK(hipMemcpy(got.data(), slots, NL * 64, hipMemcpyDeviceToHost)); CK(hipFree(slots));

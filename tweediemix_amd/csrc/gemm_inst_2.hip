@@ -1,0 +1,13 @@
+// gemm_inst_2.hip -- instantiations of gemm_conv_kernel (gemm_kernel.h) for one group of tilings
+#include "gemm_kernel.h"
+
+namespace tmix_gemm {
+
+int launch_group2(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st) {
+    if (cfg == 7) return conv ? launch_cfg<128, 160, 4, 1, 2, 1>(p, batch, st) : launch_cfg<128, 160, 4, 1, 2, 0>(p, batch, st);
+    if (cfg == 12) return conv ? launch_cfg<128, 160, 4, 1, 4, 1>(p, batch, st) : launch_cfg<128, 160, 4, 1, 4, 0>(p, batch, st);
+    if (cfg == 13) return conv ? launch_cfg<64, 160, 1, 5, 4, 1>(p, batch, st) : launch_cfg<64, 160, 1, 5, 4, 0>(p, batch, st);
+    return -999;
+}
+
+}  // namespace tmix_gemm

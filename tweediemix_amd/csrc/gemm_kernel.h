@@ -1,0 +1,1031 @@
+// gemm_kernel.h -- bf16 MFMA GEMM (C = A * W^T) and 3x3 NHWC implicit-GEMM convolution for gfx950.
+//
+// One templated mainloop <BM, BN, WM x WN waves, NS stages> serves both:
+//   * operands are staged HBM->LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into an
+//     NS-deep ring of [rows][64] bf16 tiles; the loop keeps NS-2 whole K-tiles in flight across the
+//     per-tile barrier with COUNTED s_waitcnt vmcnt(N) + raw s_barrier (never a draining __syncthreads),
+//     because these GEMMs are latency-bound, not MFMA-bound, with a one-tile prefetch distance;
+//   * the LDS image is XOR-swizzled: 16-byte chunk c of row r lives at chunk position c ^ ((r>>1)&7).
+//     LDS-DMA destinations are lane-linear, so the permutation is applied to each lane's SOURCE address
+//     and undone on the ds_read_b128 side; it is conflict-free for the 16-lane service groups of
+//     ds_read_b128 with 32-row MFMA fragments;
+//   * v_mfma_f32_32x32x16_bf16, wave tile (BM/WM) x (BN/WN), fp32 accumulation;
+//   * the convolution differs only in how a lane finds its source address (im2col on the fly: K-tile kt
+//     is tap kt / (Cin/64), channels (kt % (Cin/64))*64..+63 of the shifted pixel; padding taps read a
+//     zeros via the buffer bounds check); stride-2 and nearest-x2 upsampling are folded into the gather;
+//   * fused epilogues: bias, per-row-group bias (time embedding), residual add, GEGLU, transposed store
+//     (V^T for the attention kernel), per-batch weight sets (concept routing).
+//
+// MFMA roofline: 2*M*N*K flops per launch against the 2.5 PFLOP/s dense bf16 peak.
+#pragma once
+#include "common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+// The kernel template is instantiated in gemm_inst_*.hip (one group of tilings per translation unit, built in parallel);
+// gemm_conv.hip holds the host entry points and the tiling switch.
+namespace tmix_gemm {
+
+constexpr int BK = 64;
+typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
+
+static __device__ __forceinline__ float xor32_sum(float x) {      // x + (value of lane ^ 32)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct Params {
+    const bf16_t* A; int64_t lda, strideA;
+    const bf16_t* W; int64_t ldw, strideW;
+    bf16_t* C; int64_t ldc, strideC;
+    const float* bias; int64_t strideBias;
+    const bf16_t* R; int64_t ldr, strideR;
+    const float* rgb; int rows_per_group;
+    bf16_t* Ct; int64_t ldct, strideCt; int n_trans_begin;
+    int M, N, K, tiles_m, tiles_n, group_m, epilogue;
+    unsigned bytesA, bytesW;          // extents of one batch slice (buffer bounds)
+    float* stats_out; int64_t strideStatsOut, ldStatsOut;      // LayerNorm producer side: float2 [tiles_n][ld] partial sums
+    const float* ln_stats; int64_t strideLnStats, ldLnStats; const float* ln_colsum; int64_t strideLnColsum;   // consumer side
+    float ln_inv_c, ln_eps; int ln_parts;
+    // convolution geometry (CONV only)
+    int H, Wd, Cin, Ho, Wo, mode, ntaps;
+    unsigned long long* prof; int prof_detail;   // in-situ timing slot (common.h) or NULL
+    int wide;                         // bit 0 / 1 / 2: the C / GEGLU / Ct stores may use the LDS-staged 16-byte form
+    const unsigned char* scaleA; const unsigned char* scaleW; int64_t strideScaleA, strideScaleW;   // fp8: E8M0 exponent per A row / W row
+};
+
+// LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
+// address is ONE 32-bit VGPR that stays constant across K-tiles (the K advance rides in the scalar soffset), and
+// out-of-range offsets read as zero, which is how convolution padding taps are produced (no zero page, no selects).
+static __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LW = 1 adds a LOADER wave to the WM x WN math waves (wave specialisation): measured on this chip (tools/ubench/dma_issue),
+// an LDS-DMA instruction blocks the issuing wave for ~100 cycles and a wave's own MFMAs queue up behind its DMA issue
+// (8 DMA + 32 MFMA per wave: 0.96 us per round), whereas DMA issued by one wave overlaps the MFMAs of OTHER waves almost
+// perfectly (the same work split as 1 loader + 4 math waves: 0.53 us).  So with LW the math waves never touch VMEM in the
+// K loop: the loader streams every K-tile (all (BM+BN)/8 instructions), waits for it with a counted vmcnt, and the
+// per-iteration s_barrier hands it over.
+// PH = 1 selects the PHASE-OFFSET mainloop (8 waves, two per SIMD): the K loop advances in 32-wide slices through a
+// four-slot LDS ring (two slices stay in flight across every barrier), and each slice is a LOAD segment (LDS-DMA issue for
+// slice s+3, fragment reads of slice s) followed by an MFMA segment (16 x v_mfma_f32_32x32x16_bf16 on a 128x64 wave tile at
+// raised priority).  The second wave of every SIMD (waves 4-7) runs one barrier behind the first, so on each SIMD one wave
+// issues DMA / ds_read while its partner keeps the matrix pipe busy -- an LDS-DMA instruction blocks its OWN wave's issue
+// for ~100 cycles (tools/ubench/dma_issue), which is what held the lock-step loop below at ~50 % of the MFMA rate.
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0>
+// (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
+// waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
+__global__ void __launch_bounds__((WM * WN + LW) * 64, LW ? 3 : (WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
+gemm_conv_kernel(const Params p) {
+    static_assert(!PH || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
+    // PH = 2: the same loop on OCP fp8 (e4m3) operands: a slice row is still 64 bytes, i.e. 64 K values, and the eight
+    // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
+    // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
+    // scales once and the K assignment inside a 64-byte slice need only be the same for both operands.
+    constexpr bool F8 = PH == 2;
+    constexpr int EB = F8 ? 1 : 2;                     // bytes per operand element
+    constexpr int NW = WM * WN;                        // math waves
+    constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
+    constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
+    constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
+    constexpr int SLOT = (BM + BN) * 64;               // PH: one 32-wide K slice of both operands (rows of 64 bytes)
+    constexpr int RING = PH ? 4 * SLOT : NS * STAGE;   // bytes of the staging ring (the fused-LayerNorm block sits behind it)
+    constexpr int SW = LW ? 1 : NW;                    // waves that share the staging of a K-tile
+    constexpr int IA = BM / 8, IB = BN / 8;            // LDS-DMA instructions per stage (8 rows of 128 bytes each)
+    // ... per staging wave; when the waves do not divide them (64x160 over 5 waves) a surplus slot re-stages the last rows
+    // (same bytes to the same place), so every wave issues the same count and the counted vmcnt waits stay valid
+    constexpr int RA = (IA + SW - 1) / SW, RB = (IB + SW - 1) / SW;
+    constexpr int L = RA + RB;
+    static_assert(RA >= 1 && RB >= 1 && FM >= 1 && FN >= 1, "tile/wave geometry");
+    static_assert(PH || (NS - 2) * L <= 63, "vmcnt immediate");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w / WN, wc = w - wr * WN;
+    const bool prof_on = p.prof != nullptr && tid == 0;
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
+    if (prof_on) pt0 = prof_enter(p.prof, (blockIdx.x | blockIdx.y) == 0, p.prof_detail);
+    const bool loader = LW && (w == NW);               // wave-uniform role
+    const bool stager = LW ? loader : true;
+    const int sw_id = LW ? 0 : w;                      // this wave's slot among the staging waves
+
+    // Tile order: each XCD (private 4 MiB L2) owns a contiguous range of logical ids, and ids sweep GM tile-rows
+    // per tile-column, so the ~64 tiles resident on an XCD at any time form a compact GM x (64/GM) patch that
+    // shares GM A-panels and 64/GM W-panels instead of streaming one W-panel per tile through the L2.
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = p.group_m * p.tiles_n;
+    const int grp = bid / per_group;
+    const int first_m = grp * p.group_m;
+    const int gsize = min(p.tiles_m - first_m, p.group_m);
+    const int rem = bid - grp * per_group;
+    const int tile_n = rem / gsize, tile_m = first_m + (rem - tile_n * gsize);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = blockIdx.y;
+
+    const bf16_t* Ab = (const bf16_t*)((const char*)p.A + (int64_t)bz * p.strideA * EB);      // strides count elements (fp8: bytes)
+    const bf16_t* Wb = (const bf16_t*)((const char*)p.W + (int64_t)bz * p.strideW * EB);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, p.bytesW, 0x00020000);
+
+    // ---- per-lane staging sources. Wave-instruction idx = r*NW + w covers LDS rows idx*8 .. idx*8+7.
+    const int lrow = lane >> 3;
+    // per-lane offsets are 32-bit element counts off wave-uniform bases (saddr + voffset form of global_load_lds)
+    // A loader wave (LW) covers ALL rows of the tile; its per-lane offsets follow from two parity variants (the swizzle
+    // of instruction idx depends on idx & 1 only) plus a wave-uniform row advance, clamped like the per-wave arrays below.
+    auto slot_a = [&](int r) { int i = r * SW + sw_id; if constexpr (IA % SW != 0) i = min(i, IA - 1); return i; };
+    auto slot_w = [&](int r) { int i = r * SW + sw_id; if constexpr (IB % SW != 0) i = min(i, IB - 1); return i; };
+    constexpr int RAa = (LW && !CONV) ? 1 : RA, RBa = LW ? 1 : RB;
+    unsigned woff[RBa], aoff[RAa];
+    int pb[CONV ? RA : 1], py[CONV ? RA : 1], px[CONV ? RA : 1], asw[(CONV && !LW) ? RA : 1];
+    unsigned aoffp[2], amaxp[2], woffp[2], wmaxp[2], swp[2];
+    if constexpr (LW) {
+        if (loader) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const unsigned sw = ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 8;
+                swp[par] = sw;
+                woffp[par] = ((unsigned)(n0 + par * 8 + lrow) * (unsigned)p.ldw + sw) * 2u;
+                wmaxp[par] = ((unsigned)(p.N - 1) * (unsigned)p.ldw + sw) * 2u;
+                aoffp[par] = ((unsigned)(m0 + par * 8 + lrow) * (unsigned)p.lda + sw) * 2u;
+                amaxp[par] = ((unsigned)(p.M - 1) * (unsigned)p.lda + sw) * 2u;
+            }
+            if constexpr (CONV) {
+                const int hw = p.Ho * p.Wo;
+#pragma unroll
+                for (int r = 0; r < RA; ++r) {
+                    int m = m0 + r * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+                    pb[r] = m / hw; const int rem = m - pb[r] * hw;
+                    py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
+                }
+            }
+        }
+    } else
+    if (stager && !PH) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int idx = slot_w(r);
+        const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
+        int n = n0 + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
+        woff[r] = ((unsigned)n * (unsigned)p.ldw + sw) * 2u;
+    }
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int idx = slot_a(r);
+        const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;
+        int m = m0 + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+        asw[r] = sw;
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+            pb[r] = m / hw; const int rem = m - pb[r] * hw;
+            py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
+            aoff[r] = 0;
+        } else {
+            aoff[r] = ((unsigned)m * (unsigned)p.lda + sw) * 2u;
+        }
+    }
+    }
+
+    // ---- PH: a slice is (BM + BN) rows of 64 bytes; one LDS-DMA instruction covers 16 rows (lane -> row lane >> 2,
+    // 16-byte position lane & 3), and position q of row r holds source chunk q ^ ((r >> 2) & 3): the 16-lane service
+    // groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then touch 16 distinct 16-byte bank groups.
+    constexpr int PA = PH ? BM / 16 / NW : 1, PB = PH ? BN / 16 / NW : 1;      // DMA instructions per wave per slice
+    unsigned phA[PA], phW[PB];
+    if constexpr (PH) {
+        const unsigned ch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * (16 / EB));  // swizzled source chunk (elements)
+#pragma unroll
+        for (int r = 0; r < PA; ++r) {
+            int m = m0 + (r * NW + w) * 16 + (lane >> 2); if (m > p.M - 1) m = p.M - 1;
+            phA[r] = ((unsigned)m * (unsigned)p.lda + ch) * (unsigned)EB;
+        }
+#pragma unroll
+        for (int r = 0; r < PB; ++r) {
+            int n = n0 + (r * NW + w) * 16 + (lane >> 2); if (n > p.N - 1) n = p.N - 1;
+            phW[r] = ((unsigned)n * (unsigned)p.ldw + ch) * (unsigned)EB;
+        }
+    }
+    auto ph_stage = [&](int slot, int s) {
+        char* sA = smem + slot * SLOT;
+        char* sW = sA + BM * 64;
+#pragma unroll
+        for (int r = 0; r < PA; ++r) blds16(rsA, phA[r], (unsigned)s * 64u, sA + (r * NW + w) * 1024);
+#pragma unroll
+        for (int r = 0; r < PB; ++r) blds16(rsW, phW[r], (unsigned)s * 64u, sW + (r * NW + w) * 1024);
+    };
+
+    const int nk = p.K / BK;
+    int tap = 0, cc = 0;                              // conv K-tile cursor: tap (0..8), 64-channel chunk
+    const int cpt = CONV ? p.Cin / BK : 1;
+
+    // conv: the per-lane byte offset of a tap is computed once per tap (when the 64-channel cursor cc wraps);
+    // the channel chunk rides in the scalar soffset.  Padding taps get an offset beyond num_records (-> zeros).
+    unsigned cvo[RA];
+    auto conv_tap_offsets = [&]() {
+        // TMIX_CONV_T3: a (3,1,1) kernel over the first (frame) axis only -- 3 taps, kx fixed at the centre
+        const int ky = p.mode == TMIX_CONV_T3 ? tap : tap / 3, kx = p.mode == TMIX_CONV_T3 ? 1 : tap - ky * 3;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            int iy, ix; bool ok;
+            if (p.mode == TMIX_CONV_S1 || p.mode == TMIX_CONV_T3) { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else if (p.mode == TMIX_CONV_S2A) { iy = 2 * py[r] + ky; ix = 2 * px[r] + kx; ok = (iy < p.H) & (ix < p.Wd); }   // pad right / bottom only
+            else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
+                   ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
+            const unsigned sw = LW ? swp[r & 1] : (unsigned)asw[LW ? 0 : r];
+            cvo[r] = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + sw) * 2u : 0x80000000u;
+        }
+    };
+    if constexpr (CONV) { if (stager) conv_tap_offsets(); }
+
+    auto stage = [&](int buf, int kt) {
+        char* sA = smem + buf * STAGE;
+        char* sW = sA + A_TILE;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + slot_a(r) * 1024);
+            else if constexpr (LW) blds16(rsA, min(aoffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.lda), amaxp[r & 1]),
+                                          (unsigned)kt * (BK * 2), sA + r * 1024);
+            else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if constexpr (LW) blds16(rsW, min(woffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.ldw), wmaxp[r & 1]),
+                                     (unsigned)kt * (BK * 2), sW + r * 1024);
+            else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
+        }
+        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < p.ntaps) conv_tap_offsets(); } }
+    };
+
+    // ---- loader wave (LW): leaves here, before any math-wave state (accumulators, fragments) becomes live
+    if constexpr (LW) {
+        if (loader) {                                  // ---- loader wave: DMA issue + counted waits only
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) stage(s, s);
+            if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            int nxt = NS - 1;
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool more = kt + NS - 1 < nk;
+                if (more) stage(nxt, kt + NS - 1);    // its ring slot was released by the barrier that ended iteration kt-1
+                if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+            }
+            if (p.stats_out) __syncthreads();          // the math waves' statistics reduction has one more barrier
+            return;
+        }
+    }
+
+    // ---- fused LayerNorm (consumer side), part 1: the producer GEMM left ln_parts partial {sum, sum of squares}
+    // per row (one per column tile of ITS grid).  Thread t owns tile row t and tile column t: the partials (added in
+    // a fixed order -> scheduling-independent) and the weight column sum are requested here, and reduced once the
+    // prologue's K-tiles are in flight (ln_reduce), so their latency rides under the prologue.  The results go to a
+    // small LDS block behind the staging ring, already in MFMA-operand form (see part 2).
+    uint4* ln_mfrag = (uint4*)(smem + RING);          // [BM] -mean pieces, [BN] colsum pieces, then float rstd[BM]
+    uint4* ln_cfrag = ln_mfrag + BM;
+    float* ln_rs = (float*)(ln_cfrag + BN);
+    constexpr int PU = 16;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x2 lnv[PU];
+    float ln_cs = 0.f;
+    const bool ln_on = p.ln_stats != nullptr;
+    if (ln_on) {
+        // buffer loads: the per-lane offset is the row, the partial index rides in the scalar offset
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ln_stats + (int64_t)bz * p.strideLnStats), 0,
+                                                                              (int)(p.ln_parts * p.ldLnStats * 8), 0x00020000);
+        if (tid < BM) {
+            const int lnm = min(m0 + tid, p.M - 1);
+#pragma unroll
+            for (int q = 0; q < PU; ++q)
+                if (q < p.ln_parts) lnv[q] = __builtin_amdgcn_raw_buffer_load_b64(rsS, lnm * 8, q * (int)p.ldLnStats * 8, 0);
+        }
+        if (tid < BN) ln_cs = (p.ln_colsum + (int64_t)bz * p.strideLnColsum)[min(n0 + tid, p.N - 1)];
+    }
+    // x = x1 + x2 + x3 (bf16 pieces by truncation, exact residuals): operand halves {x1,x1,x2,0 | x1,x3,x2,0} for -mean
+    // and {x1,x2,x1,0 | x3,x1,x2,0} for colsum pair up to the six products x_a * y_b with a + b <= 4 (~24 bits)
+    auto ln_reduce = [&]() {
+        if (!ln_on) return;
+        if (tid < BM) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < PU; ++q)
+                if (q < p.ln_parts) { s1 += __uint_as_float(lnv[q].x); s2 += __uint_as_float(lnv[q].y); }
+            const float mean = s1 * p.ln_inv_c;
+            ln_rs[tid] = rsqrtf(fmaxf(s2 * p.ln_inv_c - mean * mean, 0.f) + p.ln_eps);
+            const float x = -mean;
+            const unsigned x1 = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(x1);
+            const unsigned x2 = __float_as_uint(r1) & 0xffff0000u;
+            const unsigned x3 = __float_as_uint(r1 - __uint_as_float(x2)) & 0xffff0000u;
+            ln_mfrag[tid] = make_uint4((x1 >> 16) | x1, x2 >> 16, (x1 >> 16) | x3, x2 >> 16);
+        }
+        if (tid < BN) {
+            const unsigned x1 = __float_as_uint(ln_cs) & 0xffff0000u;
+            const float r1 = ln_cs - __uint_as_float(x1);
+            const unsigned x2 = __float_as_uint(r1) & 0xffff0000u;
+            const unsigned x3 = __float_as_uint(r1 - __uint_as_float(x2)) & 0xffff0000u;
+            ln_cfrag[tid] = make_uint4((x1 >> 16) | x2, x1 >> 16, (x3 >> 16) | x1, x2 >> 16);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool trans = (p.n_trans_begin >= 0) && (n0 >= p.n_trans_begin);
+    // transposed tiles: square wave tiles swap the two LDS sources in the main loop (the lane then owns 4 consecutive m of one
+    // n); every other tiling accumulates as usual and transposes while staging the stores through LDS
+    constexpr bool SQ = (FM == FN && TM == TN) && !PH;
+    const bool tswap = trans && SQ;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int fsw = (lane >> 1) & 7;                  // f(row) for fragment rows base + (lane & 31)
+
+    // One MFMA body for both store orientations: acc[i][j] = mfma(b[j], a[i]) yields D[rows of b][rows of a], and
+    // a lane holds 4 consecutive D-rows for one D-column.  Row-major tiles take a = A-tile, b = W-tile fragments
+    // (lane: 4 consecutive n for one m); transposed tiles swap the two LDS sources (square wave tiles only), so
+    // acc[i][j] then belongs to W-fragment i x A-fragment j and a lane holds 4 consecutive m for one n.
+    const int offA = (wr * TM + l31) * 128, offW = A_TILE + (wc * TN + l31) * 128;
+    const int off_a = tswap ? offW : offA, off_b = tswap ? offA : offW;
+    auto compute = [&](int buf) {
+        const char* pa = smem + buf * STAGE + off_a;
+        const char* pb = smem + buf * STAGE + off_b;
+        // fragments of k-step kk+1 are requested before the MFMAs of k-step kk issue (register double buffer)
+        frag_ab a[2][FM], b[2][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[0][i] = *(const frag_ab*)(pa + i * 32 * 128 + ((lhi ^ fsw) << 4));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + ((lhi ^ fsw) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                const int sw = (((kk + 1) * 2 + lhi) ^ fsw) << 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[(kk + 1) & 1][i] = *(const frag_ab*)(pa + i * 32 * 128 + sw);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[(kk + 1) & 1][j] = *(const frag_ab*)(pb + j * 32 * 128 + sw);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk & 1][j], a[kk & 1][i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
+    const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
+    const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU && !(p.wide & 1);
+    constexpr bool PREF = FM * FN <= 4;               // large wave tiles have no registers to spare for it
+    uint2 rres[PREF ? FM : 1][PREF ? FN : 1][4];
+    auto prefetch_residual = [&]() {
+        if constexpr (PREF)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            int m = m0 + wr * TM + i * 32 + l31; if (m > p.M - 1) m = p.M - 1;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int n = n0 + wc * TN + j * 32 + g * 8 + lhi * 4; if (n > p.N - 4) n = p.N - 4;
+                    rres[i][j][g] = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
+                }
+        }
+    };
+    // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
+    if constexpr (PH) {
+        constexpr int PL = PA + PB;                    // this wave's DMA instructions per slice
+        static_assert(2 * PL <= 63, "vmcnt immediate");
+        const int ns = p.K / (64 / EB);
+        const int offA4 = (wr * TM + l31) * 64, offW4 = BM * 64 + (wc * TN + l31) * 64;
+        typedef int v8i_t __attribute__((ext_vector_type(8)));
+        int f8sA[F8 ? FM : 1], f8sW[F8 ? FN : 1];      // fp8: this lane's row scales, the E8M0 byte replicated into all four byte lanes
+        if constexpr (F8) {
+            const unsigned char* sa = p.scaleA + (int64_t)bz * p.strideScaleA;
+            const unsigned char* sw = p.scaleW + (int64_t)bz * p.strideScaleW;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) f8sA[i] = (int)(sa[min(m0 + wr * TM + i * 32 + l31, p.M - 1)] * 0x01010101u);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) f8sW[j] = (int)(sw[min(n0 + wc * TN + j * 32 + l31, p.N - 1)] * 0x01010101u);
+        }
+        const int f4 = (lane >> 2) & 3;                // (row >> 2) & 3 of fragment row base + (lane & 31)
+        const int q0 = ((0 + lhi) ^ f4) << 4, q1 = ((2 + lhi) ^ f4) << 4;      // k-step 0 / 1 of the slice
+        const int grp = w >> 2;                        // waves 4-7 (the second wave of each SIMD) run one barrier behind
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < ns) ph_stage(s, s);
+        ln_reduce();
+        if (ns >= 3) wait_vmcnt<2 * PL>(); else if (ns == 2) wait_vmcnt<PL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (prof_on) pt1 = prof_now();
+        if (grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        // One slice: LOAD segment (fragment reads of slice s; the wait that makes slice s + 1 visible), barrier, MFMA
+        // segment, barrier.  The LDS-DMA instructions of slice s + 3 are issued INSIDE the MFMA cluster, one after every
+        // fourth MFMA: among MFMAs a DMA costs ~60 issue cycles and about half of it hides behind the 32-cycle matrix
+        // op, while beside the ds_reads of the LOAD segment each cost 100-185 cycles and made that segment (not the MFMA
+        // segment of the partner wave) the length of every barrier interval.  Its ring slot is the one slice s - 1 was
+        // read from, released two barriers ago.
+        auto slice = [&](int s, auto stage_tag) {
+            constexpr bool ST = decltype(stage_tag)::value;
+            const char* pa = smem + (s & 3) * SLOT + offA4;
+            const char* pw = smem + (s & 3) * SLOT + offW4;
+            frag_ab a[2][FM], b[2][FN];
+            v8i_t a8[F8 ? FM : 1], b8[F8 ? FN : 1];
+            if constexpr (F8) {                       // lane (row, half): bytes [32 * half, 32 * half + 32) of the row's 64-byte slice
+                const int c0 = ((2 * lhi) ^ f4) << 4, c1 = ((2 * lhi + 1) ^ f4) << 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const uint4 lo = *(const uint4*)(pa + i * 32 * 64 + c0), hi = *(const uint4*)(pa + i * 32 * 64 + c1);
+                    a8[i] = (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const uint4 lo = *(const uint4*)(pw + j * 32 * 64 + c0), hi = *(const uint4*)(pw + j * 32 * 64 + c1);
+                    b8[j] = (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                }
+            } else {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) { a[0][i] = *(const frag_ab*)(pa + i * 32 * 64 + q0); a[1][i] = *(const frag_ab*)(pa + i * 32 * 64 + q1); }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { b[0][j] = *(const frag_ab*)(pw + j * 32 * 64 + q0); b[1][j] = *(const frag_ab*)(pw + j * 32 * 64 + q1); }
+            }
+            // slice s + 1 must have landed (for every wave) before the barrier in front of its first reader; in flight
+            // here: slices s + 1 and s + 2 (slice s + 3 is issued below)
+            if (s + 2 < ns) wait_vmcnt<PL>(); else wait_vmcnt<0>();
+            if (PREF && s == ns - 1 && Rb && plain_epi) prefetch_residual();     // rides under the last MFMA segment
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA segment
+            __builtin_amdgcn_s_setprio(1);
+            char* sA = smem + ((s + 3) & 3) * SLOT;
+            char* sW = sA + BM * 64;
+            constexpr int KS = F8 ? 1 : 2;                          // MFMA k-steps per slice
+            constexpr int NMF = KS * FM * FN, GAP = NMF / PL;       // one DMA after every GAP-th MFMA
+            int issued = 0;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        if constexpr (F8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, f8sW[j], 0, f8sA[i]);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
+                        const int idx = (kk * FM + i) * FN + j;
+                        if constexpr (ST) {
+                            if (idx % GAP == (GAP > 1 ? 1 : 0) && issued < PL) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (issued < PA) blds16(rsA, phA[issued], (unsigned)(s + 3) * 64u, sA + (issued * NW + w) * 1024);
+                                else             blds16(rsW, phW[issued - PA], (unsigned)(s + 3) * 64u, sW + ((issued - PA) * NW + w) * 1024);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++issued;
+                            }
+                        }
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        };
+        int s = 0;
+        for (; s + 3 < ns; ++s) slice(s, std::true_type{});
+        for (; s < ns; ++s) slice(s, std::false_type{});
+        if (!grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    } else
+    if constexpr (LW) {
+        ln_reduce();                                   // ---- math waves: LDS reads + MFMA only
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (prof_on) pt1 = prof_now();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
+            compute(cur);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+        }
+    } else {
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    ln_reduce();
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (prof_on) pt1 = prof_now();
+    int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + NS - 1 < nk;
+        if (more) stage(nxt, kt + NS - 1);
+        if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
+        compute(cur);
+        if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+    }
+
+    if (prof_on) pt2 = prof_now();
+    // ---------------------------------------------------------------- fused LayerNorm (consumer side), part 2
+    // A was the raw row x; with W' = W*gamma:  Linear(LN(x))[m][n] = rstd_m * (acc[m][n] - mean_m * colsum_n) + t_n
+    // (t_n arrives as the bias).  The rank-1 term -mean_m * colsum_n is one more MFMA k-step per fragment, fed from
+    // the operand pieces ln_reduce left in LDS (visible: every wave has passed >= 2 barriers since); rstd_m is
+    // applied as the multiplier of the bias FMA in the epilogue.
+    float rs_row[FM];                                 // row-major tiles: rstd of this lane's row per fragment
+#pragma unroll
+    for (int i = 0; i < FM; ++i) rs_row[i] = 1.f;
+    if (p.ln_stats) {
+        // fragments follow the LDS sources of the main loop: a[i] <- rows of off_a's tile, b[j] <- rows of off_b's
+        const uint2* srcA = (const uint2*)(ln_mfrag + wr * TM + l31) + lhi;
+        const uint2* srcW = (const uint2*)(ln_cfrag + wc * TN + l31) + lhi;
+        const uint2* src_a = tswap ? srcW : srcA;
+        const uint2* src_b = tswap ? srcA : srcW;
+        frag_ab fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const uint2 h = src_a[i * 64];
+            uint4 u = make_uint4(h.x, h.y, 0u, 0u);
+            fa[i] = *(frag_ab*)&u;
+            if (!tswap) rs_row[i] = ln_rs[wr * TM + i * 32 + l31];
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const uint2 h = src_b[j * 64];
+            uint4 u = make_uint4(h.x, h.y, 0u, 0u);
+            fb[j] = *(frag_ab*)&u;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+
+    // 32x32 accumulator: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    // ---- LDS-staged ("wide") stores.  In the accumulator layout a lane owns 4 consecutive outputs of ONE row, so a store
+    // instruction scatters 64 x 8 bytes over 32 rows: 32 partial-line requests per instruction, and the epilogue of a
+    // 256 x 256 tile took 14-24 us (a quarter to a half of the whole workgroup; tools/gemm_lab `tl`).  The staging ring is
+    // free by now: each wave copies a 32-row block of its tile to a private LDS patch (rows padded by 16 bytes), reads it
+    // back row-major -- 8 consecutive outputs per lane, 4-8 lanes per row -- and does bias / LayerNorm scale / activation /
+    // residual there, so residual loads and C stores are 16 bytes per lane and 64-128 contiguous bytes per row.  Values and
+    // operation order per element are those of the narrow path (bit-identical C); only the row statistics add in a new order.
+    constexpr int STG_MAX = 32 * (2 * 32 * 4 + 16);               // bytes of LDS patch per wave (largest chunk: 64 fp32 columns)
+    if (trans) {
+        if constexpr (!SQ) {
+            // accumulators in the usual orientation (lane: 4 consecutive n of row m = lane & 31): every 32 x (FM * 32) block
+            // [n][m] is written to the wave's LDS patch two bytes at a time, read back as rows of Ct and stored 16 bytes per lane
+            // (launch() only routes a transposed region here when the 16-byte form is allowed, p.wide & 4)
+            bf16_t* Ct = p.Ct + (int64_t)bz * p.strideCt;
+            constexpr int SR = FM * 64 + 16, LPR = FM * 4, RPI = 64 / LPR, NP = 32 / RPI;
+            static_assert(32 * SR <= STG_MAX && 64 % LPR == 0, "transposed staging patch");
+            char* stg = smem + w * STG_MAX;
+            const int rr = lane / LPR, cc = (lane % LPR) * 8;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wc * TN + j * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias && nb < p.N) { const float4 b4 = *(const float4*)(bias + nb + g * 8 + lhi * 4); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            *(bf16_t*)(stg + (g * 8 + lhi * 4 + r) * SR + (i * 32 + l31) * 2) = f2bf(fmaf(acc[i][j][g * 4 + r], rs_row[i], bv[r]));
+                }
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int r = ps * RPI + rr, n = nb + r, m = m0 + wr * TM + cc;
+                    const uint4 v = *(const uint4*)(stg + r * SR + cc * 2);
+                    if (n >= p.N || m >= p.M) continue;
+                    bf16_t* dst = Ct + (int64_t)(n - p.n_trans_begin) * p.ldct + m;
+                    if (m + 8 <= p.M) *(uint4*)dst = v;
+                    else {
+                        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                        for (int k = 0; k < 8 && m + k < p.M; ++k) dst[k] = (bf16_t)(u[k >> 1] >> ((k & 1) * 16));
+                    }
+                }
+            }
+            if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+            return;
+        }
+        if constexpr (SQ) {
+            bf16_t* Ct = p.Ct + (int64_t)bz * p.strideCt;
+            if (p.wide & 4) {
+                constexpr int CF = (FN % 2 == 0) ? 2 : 1, SR = CF * 64 + 16, LPR = CF * 4, RPI = 64 / LPR, NP = 32 / RPI;
+                char* stg = smem + w * STG_MAX;
+                const int rr = lane / LPR, cc = (lane % LPR) * 8;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {             // W fragment: 32 rows of Ct
+                    const int nl = n0 + wc * TN + i * 32 + l31;
+                    const float bv = (bias && nl < p.N) ? bias[nl] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < FN / CF; ++c) {
+#pragma unroll
+                        for (int jj = 0; jj < CF; ++jj)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int j = c * CF + jj, ml = wr * TM + j * 32 + g * 8 + lhi * 4;
+                                const float4 rs = p.ln_stats ? *(const float4*)(ln_rs + ml) : make_float4(1.f, 1.f, 1.f, 1.f);
+                                uint2 v;
+                                v.x = pack_bf2(fmaf(acc[i][j][g * 4 + 0], rs.x, bv), fmaf(acc[i][j][g * 4 + 1], rs.y, bv));
+                                v.y = pack_bf2(fmaf(acc[i][j][g * 4 + 2], rs.z, bv), fmaf(acc[i][j][g * 4 + 3], rs.w, bv));
+                                *(uint2*)(stg + l31 * SR + (jj * 32 + g * 8 + lhi * 4) * 2) = v;
+                            }
+#pragma unroll
+                        for (int ps = 0; ps < NP; ++ps) {
+                            const int r = ps * RPI + rr, n = n0 + wc * TN + i * 32 + r, m = m0 + wr * TM + c * CF * 32 + cc;
+                            const uint4 v = *(const uint4*)(stg + r * SR + cc * 2);
+                            if (n >= p.N || m >= p.M) continue;
+                            bf16_t* dst = Ct + (int64_t)(n - p.n_trans_begin) * p.ldct + m;
+                            if (m + 8 <= p.M) *(uint4*)dst = v;
+                            else {
+                                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                                for (int k = 0; k < 8 && m + k < p.M; ++k) dst[k] = (bf16_t)(u[k >> 1] >> ((k & 1) * 16));
+                            }
+                        }
+                    }
+                }
+                if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {                 // W fragment (output row of Ct)
+                const int n = n0 + wc * TN + i * 32 + l31;
+                if (n >= p.N) continue;
+                const float bv = bias ? bias[n] : 0.f;
+                bf16_t* row = Ct + (int64_t)(n - p.n_trans_begin) * p.ldct;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)               // A fragment (4 consecutive m per register group)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ml = wr * TM + j * 32 + g * 8 + lhi * 4, m = m0 + ml;
+                        if (m >= p.M) continue;
+                        const float4 rs = p.ln_stats ? *(const float4*)(ln_rs + ml) : make_float4(1.f, 1.f, 1.f, 1.f);
+                        const float o0 = fmaf(acc[i][j][g * 4 + 0], rs.x, bv), o1 = fmaf(acc[i][j][g * 4 + 1], rs.y, bv);
+                        const float o2 = fmaf(acc[i][j][g * 4 + 2], rs.z, bv), o3 = fmaf(acc[i][j][g * 4 + 3], rs.w, bv);
+                        if (m + 3 < p.M && ((p.ldct & 3) == 0)) {
+                            uint2 v;
+                            v.x = pack_bf2(o0, o1);
+                            v.y = pack_bf2(o2, o3);
+                            *(uint2*)(row + m) = v;
+                        } else {
+                            const float o[4] = {o0, o1, o2, o3};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (m + r < p.M) row[m + r] = f2bf(o[r]);
+                        }
+                    }
+            }
+        }
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+        return;
+    }
+
+    bf16_t* Cb = p.C + (int64_t)bz * p.strideC;
+    if (p.epilogue == TMIX_EPI_GEGLU) {
+        // weight rows are interleaved in 16-row groups [value_j | gate_j]: within a 32-row fragment, accumulator
+        // register groups g=0,1 (rows 0-15) are the value half and g=2,3 (rows 16-31) the gate half.
+        if (p.wide & 2) {
+            char* stg = smem + w * STG_MAX;
+            auto chunk = [&](int i, int j0, auto cf_tag) {       // CF fragments -> CF * 16 output columns of one 32-row block
+                constexpr int CF = decltype(cf_tag)::value, OC = CF * 16, SR = OC * 2 + 16, LPR = OC / 8, RPI = 64 / LPR, NP = 32 / RPI;
+                const int rr = lane / LPR, cc = (lane % LPR) * 8;
+#pragma unroll
+                for (int jj = 0; jj < CF; ++jj) {
+                    const int j = j0 + jj, nb = n0 + wc * TN + j * 32;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int nv = nb + g * 8 + lhi * 4;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
+                            if (bias && nb < p.N) { a = fmaf(a, rs_row[i], bias[nv + r]); gt = fmaf(gt, rs_row[i], bias[nv + 16 + r]); }
+                            else { a *= rs_row[i]; gt *= rs_row[i]; }
+                            o[r] = a * gelu_erf_f(gt);
+                        }
+                        uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                        *(uint2*)(stg + l31 * SR + (jj * 16 + g * 8 + lhi * 4) * 2) = v;
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int r = ps * RPI + rr, m = m0 + wr * TM + i * 32 + r;
+                    const uint4 v = *(const uint4*)(stg + r * SR + cc * 2);
+                    const int nb = n0 + wc * TN + (j0 + cc / 16) * 32;              // weight row of the fragment this lane's columns come from
+                    if (m >= p.M || nb >= p.N) continue;
+                    *(uint4*)(Cb + (int64_t)m * p.ldc + (n0 + wc * TN) / 2 + j0 * 16 + cc) = v;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                constexpr int C4 = FN / 4, R4 = FN % 4;
+#pragma unroll
+                for (int c = 0; c < C4; ++c) chunk(i, c * 4, std::integral_constant<int, 4>{});
+                if constexpr (R4 >= 2) chunk(i, C4 * 4, std::integral_constant<int, 2>{});
+                if constexpr (R4 & 1) chunk(i, FN - 1, std::integral_constant<int, 1>{});
+            }
+            if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wr * TM + i * 32 + l31;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wc * TN + j * 32;               // weight-row index of this fragment
+                if (nb >= p.N) continue;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int nv = nb + g * 8 + lhi * 4;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
+                        if (bias) { a = fmaf(a, rs_row[i], bias[nv + r]); gt = fmaf(gt, rs_row[i], bias[nv + 16 + r]); }
+                        else { a *= rs_row[i]; gt *= rs_row[i]; }
+                        o[r] = a * gelu_erf_f(gt);
+                    }
+                    uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                    *(uint2*)(Cb + (int64_t)m * p.ldc + nb / 2 + g * 8 + lhi * 4) = v;
+                }
+            }
+        }
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+        return;
+    }
+    // LayerNorm producer side: {sum, sum of squares} of every row of this tile AS STORED (bf16-rounded), reduced over
+    // the wave's fragments, the lane pair and the WG's wave columns in a fixed order, then written (not accumulated)
+    // to stats_out[tile_n][m] -- one partial per column tile; the consumer adds the tiles_n partials.
+    float2* sto = p.stats_out ? (float2*)(p.stats_out + (int64_t)bz * p.strideStatsOut) : nullptr;
+    if (p.wide & 1) {
+        char* stg = smem + w * STG_MAX;
+        float2* redw = (float2*)(smem + NW * STG_MAX);           // [WN][BM] row-statistics exchange, behind the patches
+        const bool f32out = p.epilogue == TMIX_EPI_F32OUT;
+        // row statistics: partial {sum, sum of squares} per (32-row block, pass); the 64-column chunks (8 lanes per row, 4
+        // passes of 8 rows) and a trailing 32-column chunk (4 lanes per row, 2 passes of 16 rows) map lanes to rows differently
+        float sa1[FM][4], sa2[FM][4], sb1[FM][2], sb2[FM][2];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sa1[i][q] = 0.f; sa2[i][q] = 0.f; }
+            sb1[i][0] = sb1[i][1] = sb2[i][0] = sb2[i][1] = 0.f;
+        }
+        auto chunk = [&](int j0, auto cf_tag) {                  // CF fragments = CF * 32 fp32 columns of every 32-row block
+            constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, SR = CW * 4 + 16, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
+            const int rr = lane / LPR, cc = (lane % LPR) * 8;
+            const int nc = n0 + wc * TN + j0 * 32 + cc;
+            const bool ncok = nc < p.N;
+            float bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = 0.f;
+            if (bias && ncok) {
+                const float4 b0 = *(const float4*)(bias + nc), b1 = *(const float4*)(bias + nc + 4);
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int mb = m0 + wr * TM + i * 32;
+                uint4 rv[NP];
+                if (Rb) {
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const int m = mb + ps * RPI + rr;
+                        if (m < p.M && ncok) rv[ps] = *(const uint4*)(Rb + (int64_t)m * p.ldr + nc);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < CF; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(float4*)(stg + l31 * SR + (jj * 32 + g * 8 + lhi * 4) * 4) =
+                            make_float4(acc[i][j0 + jj][g * 4 + 0], acc[i][j0 + jj][g * 4 + 1], acc[i][j0 + jj][g * 4 + 2], acc[i][j0 + jj][g * 4 + 3]);
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int r = ps * RPI + rr, m = mb + r;
+                    const float4 v0 = *(const float4*)(stg + r * SR + cc * 4), v1 = *(const float4*)(stg + r * SR + cc * 4 + 16);
+                    if (m >= p.M || !ncok) continue;
+                    float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    if (bias) { const float rs = p.ln_stats ? ln_rs[wr * TM + i * 32 + r] : 1.f;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) o[k] = fmaf(o[k], rs, bv[k]); }
+                    else if (p.ln_stats) { const float rs = ln_rs[wr * TM + i * 32 + r];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) o[k] *= rs; }
+                    if (p.rgb) {
+                        const float* rg = p.rgb + (int64_t)(m / p.rows_per_group) * p.N + nc;
+                        const float4 b0 = *(const float4*)rg, b1 = *(const float4*)(rg + 4);
+                        o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+                    }
+                    if (p.epilogue == TMIX_EPI_GELU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = gelu_erf_f(o[k]);
+                    } else if (p.epilogue == TMIX_EPI_QUICKGELU) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = o[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * o[k]));
+                    }
+                    if (Rb) {
+                        const unsigned u[4] = {rv[ps].x, rv[ps].y, rv[ps].z, rv[ps].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { o[2 * k] += bf2f((bf16_t)(u[k] & 0xffff)); o[2 * k + 1] += bf2f((bf16_t)(u[k] >> 16)); }
+                    }
+                    if (f32out) {
+                        float* dst = (float*)p.C + (int64_t)bz * p.strideC + (int64_t)m * p.ldc + nc;
+                        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                        *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    } else {
+                        uint4 v;
+                        v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
+                        *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
+                        if (sto) {                                 // statistics of the values AS STORED
+                            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+                                a1 += lo + hi; a2 = fmaf(lo, lo, a2); a2 = fmaf(hi, hi, a2);
+                            }
+                            if constexpr (CF == 2) { sa1[i][ps] += a1; sa2[i][ps] += a2; } else { sb1[i][ps] += a1; sb2[i][ps] += a2; }
+                        }
+                    }
+                }
+            }
+        };
+        // chunks of two fragments (64 columns: 8 lanes x 16 bytes per row), a last single one when FN is odd
+        constexpr int C2 = FN / 2;
+#pragma unroll
+        for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{});
+        if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{});
+        if (sto) {
+            // a row's partials sit in the lanes that stored its columns: reduce over those lanes (fixed butterfly order), the
+            // group's first lane owns the row; the 32-column chunk's owners then add to the same slot (same wave: LDS in order)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (C2 > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float a1 = sa1[i][q], a2 = sa2[i][q];
+#pragma unroll
+                        for (int off = 1; off < 8; off <<= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
+                        if ((lane & 7) == 0) redw[wc * BM + wr * TM + i * 32 + q * 8 + (lane >> 3)] = make_float2(a1, a2);
+                    }
+                }
+                if constexpr (FN & 1) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float b1 = sb1[i][q], b2 = sb2[i][q];
+#pragma unroll
+                        for (int off = 1; off < 4; off <<= 1) { b1 += __shfl_xor(b1, off); b2 += __shfl_xor(b2, off); }
+                        if ((lane & 3) == 0) {
+                            float2* dst = redw + wc * BM + wr * TM + i * 32 + q * 16 + (lane >> 2);
+                            if constexpr (C2 > 0) { const float2 t = *dst; *dst = make_float2(t.x + b1, t.y + b2); }
+                            else *dst = make_float2(b1, b2);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float2 t = redw[tid];
+#pragma unroll
+                for (int c = 1; c < WN; ++c) { const float2 u = redw[c * BM + tid]; t.x += u.x; t.y += u.y; }
+                sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
+            }
+        }
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+        return;
+    }
+    float2* red = (float2*)smem;                                // [WN][BM]: the staging ring is free by now
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wr * TM + i * 32 + l31;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < p.M) {
+        const float* rg = p.rgb ? p.rgb + (int64_t)(m / p.rows_per_group) * p.N : nullptr;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wc * TN + j * 32 + g * 8 + lhi * 4;
+                if (n >= p.N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[i][j][g * 4 + r];
+                if (bias) { const float4 b4 = *(const float4*)(bias + n);
+                            o[0] = fmaf(o[0], rs_row[i], b4.x); o[1] = fmaf(o[1], rs_row[i], b4.y);
+                            o[2] = fmaf(o[2], rs_row[i], b4.z); o[3] = fmaf(o[3], rs_row[i], b4.w); }
+                else if (p.ln_stats) { o[0] *= rs_row[i]; o[1] *= rs_row[i]; o[2] *= rs_row[i]; o[3] *= rs_row[i]; }
+                if (rg)   { const float4 b4 = *(const float4*)(rg + n);   o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+                if (p.epilogue == TMIX_EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r]);
+                } else if (p.epilogue == TMIX_EPI_QUICKGELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = o[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * o[r]));
+                }
+                if (Rb) {
+                    uint2 rv;
+                    if constexpr (PREF) rv = rres[i][j][g];
+                    else rv = *(const uint2*)(Rb + (int64_t)m * p.ldr + n);
+                    o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
+                    o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
+                }
+                if (p.epilogue == TMIX_EPI_F32OUT) {
+                    *(float4*)((float*)p.C + (int64_t)bz * p.strideC + (int64_t)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
+                    *(uint2*)(Cb + (int64_t)m * p.ldc + n) = v;
+                    if (sto) {
+                        const float r0 = __uint_as_float(v.x << 16), r1 = __uint_as_float(v.x & 0xffff0000u);
+                        const float r2 = __uint_as_float(v.y << 16), r3 = __uint_as_float(v.y & 0xffff0000u);
+                        s1 += (r0 + r1) + (r2 + r3);
+                        s2 = fmaf(r0, r0, s2); s2 = fmaf(r1, r1, s2); s2 = fmaf(r2, r2, s2); s2 = fmaf(r3, r3, s2);
+                    }
+                }
+            }
+        }
+        if (sto) {                                     // wave-uniform; lanes l and l^32 hold the two halves of row m
+            s1 = xor32_sum(s1); s2 = xor32_sum(s2);
+            if (!lhi) red[wc * BM + wr * TM + i * 32 + l31] = make_float2(s1, s2);
+        }
+    }
+    if (sto) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float2 t = red[tid];
+#pragma unroll
+            for (int c = 1; c < WN; ++c) { const float2 u = red[c * BM + tid]; t.x += u.x; t.y += u.y; }
+            sto[(int64_t)tile_n * p.ldStatsOut + m0 + tid] = t;
+        }
+    }
+    if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+}
+
+// ------------------------------------------------------------------------------------------- launch
+struct TileCfg { int bm, bn; };
+// cfg ids (tmix.h TMIX_TILE_*): 1 = 128x128 (4 waves, 2 stages, 2 WG/CU), 2 = 256x128 (8 waves, 3 stages),
+// 3 = 128x128 (4 waves, 4 stages, 1 WG/CU), 4 = 256x256 (8 waves, 2 stages)
+// 5 = 256x128 (4 waves of 128x64, 3 stages, 1 WG/CU), 6 = 256x256 (4 waves of 128x128, 2 stages, 1 WG/CU):
+// one wave per SIMD with a large register tile -- on this chip instructions of co-resident waves do not overlap on a
+// SIMD, so MFMA utilisation is set by MFMAs per non-MFMA instruction, i.e. by the wave tile.
+// 7 = 128x160 (4 waves of 32x160, 2 stages): N = 1280 / 640 split into 160-wide tiles gives exactly 256 / 512 tiles
+// for this path's M = 4096 / 16384 GEMMs, i.e. whole rounds on 256 CUs instead of 1.25 / 2.5.
+// 8..11 = tilings 7, 2, 1, 4 with one extra LOADER wave (wave specialisation, see gemm_conv_kernel); the 4-wave tilings
+// with 128-wide wave tiles (5, 6) have no registers for a fifth wave on one of the SIMDs
+// 12 = tiling 7 (128x160) with a 4-deep ring (one workgroup per CU, three K-tiles in flight: the in-sequence loop is bound by
+// memory latency x bytes in flight, and 160-wide tiles divide N = 1280 / 640 exactly)
+// 13 = 64x160 over FIVE waves (each 64x32), 4-deep ring: 2048 x 1280 -- the half-batch launches of the 32x32 level -- is
+// exactly 256 tiles, one per CU, where 128x128 leaves 96 CUs idle (160 tiles) and 128x160 half of them
+// 14 = 256x320 over eight waves (wave tile 64x160): the GEGLU up-projection 2048 x 10240 is exactly 256 tiles, where
+// 256x256 runs 320 (a quarter-full second round); 128x320 over four waves was tried and lost to 128x160 everywhere
+// 15 = 32x160 over five waves (each 32x32): 1024 x 1280 -- one batch row per chain, the CFG-pair calls -- is 256 tiles
+// (a 5-deep ring for 13 measured the same as the 4-deep one)
+// 16 = 256x256, 17 = 256x128 with the PHASE-OFFSET mainloop (PH: eight waves, K slices of 32 through a four-slot ring, the
+// second wave of every SIMD one barrier behind the first; GEMM only, no transposed region)
+constexpr int NUM_CFG = 17;
+
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0>
+int launch_cfg(Params& p, int batch, hipStream_t st) {
+    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
+    static bool attr_set = false;   // idempotent; racing threads set the same value
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+    p.group_m = BM >= 256 ? 4 : 8;
+    if (BM >= 256 && BN >= 256) p.group_m = 8;
+    dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
+    p.prof = tmix_prof_take(&p.prof_detail);
+    kern<<<grid, (WM * WN + LW) * 64, SMEM, st>>>(p);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+
+// one launcher per group of tilings (defined in gemm_inst_<g>.hip); returns -999 when `cfg` is not in the group
+int launch_group0(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
+int launch_group1(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
+int launch_group2(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
+int launch_group3(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
+int launch_group4(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
+
+}  // namespace tmix_gemm

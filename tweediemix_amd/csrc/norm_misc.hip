@@ -497,6 +497,70 @@ extern "C" int tmix_layernorm(const void* X, void* Y, const float* gamma, const 
     return TMIX_OK;
 }
 
+// ------------------------------------------------------------------------------ fp8 row quantiser
+// one wave per row: q[r][k] = e4m3(x[r][k] * 2^-(e_r - 127)) with e_r the smallest E8M0 exponent that brings the row's largest
+// magnitude under 448 (the e4m3 maximum); an all-zero row gets e = 127 (scale 1).  The row stays in registers between the
+// maximum and the conversion (one HBM read, K <= 8192).
+__global__ void __launch_bounds__(256) quantize_fp8_rows_kernel(const bf16_t* __restrict__ X, int64_t ld, unsigned char* __restrict__ Q, int64_t ldq,
+                                                                unsigned char* __restrict__ scale, int64_t rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    constexpr int MAXV = 16;                                  // 16-byte vectors per lane: K <= 64 * 8 * 16 = 8192
+    const int nv = K >> 3;
+    uint4 v[MAXV];
+    float amax = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int c = u * 64 + lane;
+        if (c < nv) {
+            v[u] = *(const uint4*)(X + r * ld + (int64_t)c * 8);
+            const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) amax = fmaxf(amax, fmaxf(fabsf(__uint_as_float(w[k] << 16)), fabsf(__uint_as_float(w[k] & 0xffff0000u))));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    // smallest e with amax * 2^-e <= 448:  e = ceil(log2(amax / 448)); exact through the exponent / mantissa of amax / 448
+    int e = 0;
+    if (amax > 0.f) {
+        const float q = amax * (1.0f / 448.0f);
+        const unsigned bits = __float_as_uint(q);
+        e = (int)((bits >> 23) & 0xff) - 127 + ((bits & 0x7fffff) ? 1 : 0);
+        if (e < -127) e = -127;
+        if (e > 127) e = 127;
+    }
+    const float inv = __uint_as_float((unsigned)(127 - e) << 23);       // 2^-e (e in [-127, 127] -> a normal or zero-exponent float)
+    if (lane == 0) scale[r] = (unsigned char)(e + 127);
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int c = u * 64 + lane;
+        if (c < nv) {
+            const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            unsigned o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float f0 = __uint_as_float(w[2 * h] << 16) * inv, f1 = __uint_as_float(w[2 * h] & 0xffff0000u) * inv;
+                const float f2 = __uint_as_float(w[2 * h + 1] << 16) * inv, f3 = __uint_as_float(w[2 * h + 1] & 0xffff0000u) * inv;
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, pk, true);
+                o[h] = (unsigned)pk;
+            }
+            *(uint2*)(Q + r * ldq + (int64_t)c * 8) = make_uint2(o[0], o[1]);
+        }
+    }
+}
+
+extern "C" int tmix_quantize_fp8_rows(const void* X, int64_t ld, void* Q, int64_t ldq, uint8_t* scale_e8m0, int64_t rows, int K, void* stream) {
+    if (!X || !Q || !scale_e8m0) TMIX_FAIL(TMIX_EINVAL, "quantize_fp8_rows: null pointer");
+    if (rows <= 0 || K <= 0 || (K % 8) || K > 8192) TMIX_FAIL(TMIX_ESHAPE, "quantize_fp8_rows: rows=%lld K=%d (K %% 8 == 0, K <= 8192)", (long long)rows, K);
+    if (!aligned16(X) || (ld % 8) || (((uintptr_t)Q) & 7) || (ldq % 8)) TMIX_FAIL(TMIX_EALIGN, "quantize_fp8_rows: X rows must be 16-byte, Q rows 8-byte aligned");
+    quantize_fp8_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>((const bf16_t*)X, ld, (unsigned char*)Q, ldq, scale_e8m0, rows, K);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
 extern "C" int tmix_zero(void* ptr, int64_t nbytes, void* stream) {
     if (!ptr || nbytes <= 0) TMIX_FAIL(TMIX_EINVAL, "zero: null pointer / empty range");
     hipError_t e = hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream);

@@ -76,7 +76,7 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
     batch, M, K = a3.shape
     N = w3.shape[1]
-    assert a3.dtype == BF16 and w3.dtype == BF16 and a3.stride(2) == 1 and w3.stride(2) == 1 and w3.shape[2] == K
+    assert a3.dtype == w3.dtype and a3.dtype in (BF16, torch.uint8) and a3.stride(2) == 1 and w3.stride(2) == 1 and w3.shape[2] == K   # uint8 = e4m3 bytes (gemm_fp8)
     d = L.GemmDesc()
     d.A, d.lda, d.strideA = a3.data_ptr(), a3.stride(1), (a3.stride(0) if batch > 1 else 0)
     d.W, d.ldw, d.strideW = w3.data_ptr(), w3.stride(1), (w3.stride(0) if w3.shape[0] > 1 else 0)
@@ -138,6 +138,42 @@ def gemm(a, w, out=None, **kw):
         out = torch.empty(*a.shape[:-1], No, device=a.device, dtype=BF16)
     d = make_gemm_desc(a, w, out, **kw)
     L.check(lib.tmix_gemm_bf16(C.byref(d), _stream()), "tmix_gemm_bf16")
+    return out if out is not None else kw.get("out_f32")
+
+
+def quantize_fp8_rows(x, q=None, scale=None):
+    """x bf16 [..., K] (rows contiguous in K) -> (q uint8 [..., K] holding OCP e4m3 bytes, scale uint8 [...] E8M0 exponents):
+    x[r] ~= e4m3(q[r]) * 2^(scale[r] - 127)."""
+    _need_cuda(x)
+    assert x.dtype == BF16 and x.stride(-1) == 1
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if q is None:
+        q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    if scale is None:
+        scale = torch.empty(x.shape[:-1], device=x.device, dtype=torch.uint8)
+    q2 = q.view(-1, K)
+    L.check(L.load().tmix_quantize_fp8_rows(x2.data_ptr(), x2.stride(0), q2.data_ptr(), q2.stride(0), scale.data_ptr(), x2.shape[0], K,
+                                            _stream()), "tmix_quantize_fp8_rows")
+    return q, scale
+
+
+def dequantize_fp8_rows(q, scale):
+    """fp32 values of (q, scale) as tmix_gemm_fp8 reads them (tests / error measurements)."""
+    return q.view(torch.float8_e4m3fn).float() * torch.exp2(scale.float() - 127.0).unsqueeze(-1)
+
+
+def gemm_fp8(a8, sa, w8, sw, out=None, **kw):
+    """gemm() on e4m3 operands with per-row E8M0 scales (tmix_gemm_fp8): a8 [.., M, K] uint8 + sa [.., M]; w8 [.., N, K] + sw [.., N]."""
+    _need_cuda(a8, w8, sa, sw)
+    lib = L.load()
+    if out is None and kw.get("out_f32") is None:
+        N = w8.shape[-2]
+        No = N // 2 if kw.get("geglu") else (kw["n_trans_begin"] if kw.get("out_t") is not None else N)
+        out = torch.empty(*a8.shape[:-1], No, device=a8.device, dtype=BF16)
+    assert sa.dtype == torch.uint8 and sw.dtype == torch.uint8 and sa.is_contiguous() and sw.is_contiguous()
+    d = make_gemm_desc(a8, w8, out, **kw)
+    L.check(lib.tmix_gemm_fp8(C.byref(d), sa.data_ptr(), sw.data_ptr(), _stream()), "tmix_gemm_fp8")
     return out if out is not None else kw.get("out_f32")
 
 

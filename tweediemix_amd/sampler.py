@@ -71,8 +71,9 @@ class Tweediemix:
 
     def __init__(self, config, weights: UNetWeights, text_embeds, text_embeds_single, mask_provider,
                  concept_num: int, lora: bool = False, strict_reference: bool = True, use_graphs: bool = False,
-                 n_seeds: int = 1, n_streams: int = 1, vae=None):
+                 n_seeds: int = 1, n_streams: int = 1, vae=None, fp8: bool = False):
         self.config = config
+        self.fp8 = bool(fp8)          # optional: FF / QKV projections on e4m3 operands (tmix_gemm_fp8); default bf16 like the reference's fp16
         self.W = weights
         self.device = weights.device
         self.concept_num = int(concept_num)
@@ -154,10 +155,10 @@ class Tweediemix:
         B = ehs.shape[0]
         if self.n_streams > 1 and B % self.n_streams == 0 and B // self.n_streams >= self.min_rows_per_stream:
             return PlanGroup(self.W, self.h, self.w, ehs, wsel, pooled, self.add_time_ids.repeat(B, 1), routed,
-                             self.n_streams)
+                             self.n_streams, fp8=self.fp8)
         kv = KVCache(self.W, ehs, wsel)
         return UNetPlan(self.W, B, self.h, self.w, kv, pooled, self.add_time_ids.repeat(B, 1), routed=routed,
-                        row_sets=wsel if routed else None)
+                        row_sets=wsel if routed else None, fp8=self.fp8)
 
     def plan(self, kind):
         if kind not in self.plans:

@@ -118,6 +118,7 @@ class UNetWeights:
         self.cfg, self.device = cfg, torch.device(device)
         self.kind = concepts[0] if concepts else "none"
         self.K = len(concepts[1]) if concepts else 0
+        self._fp8 = {}
         dev = self.device
         t = {}
 
@@ -196,6 +197,17 @@ class UNetWeights:
 
     def __getitem__(self, k):
         return self.t[k]
+
+    def fp8(self, key, rows=None):
+        """(e4m3 bytes, E8M0 row scales) of weight `key` ([N,K], or the [R,N,K] stack gathered by `rows`), quantised once per
+        tensor by tmix_quantize_fp8_rows -- the operands of tmix_gemm_fp8 (`--dtype fp8`)."""
+        ck = (key, None if rows is None else tuple(rows))
+        if ck not in self._fp8:
+            w = self.t[key]
+            if rows is not None and list(rows) != list(range(w.shape[0])):
+                w = w[torch.tensor(list(rows), device=w.device)]
+            self._fp8[ck] = ops.quantize_fp8_rows(w.contiguous())
+        return self._fp8[ck]
 
     def nbytes(self):
         return sum(v.numel() * v.element_size() for v in self.t.values())
@@ -309,8 +321,11 @@ class UNetPlan:
 
     def __init__(self, W: UNetWeights, B: int, h: int, w: int, kv: KVCache, pooled: torch.Tensor,
                  time_ids: torch.Tensor, routed: bool = False, autotune: bool = True, row_sets=None,
-                 latent=None, eps=None, shared: bool = False, t_dev=None):
+                 latent=None, eps=None, shared: bool = False, t_dev=None, fp8: bool = False):
         self.W, self.cfg, self.B, self.h, self.w = W, W.cfg, B, h, w
+        # fp8: the attn1 q/k/v, FF up- and down-projections run as tmix_gemm_fp8 (e4m3 operands, per-row power-of-two scales);
+        # their A operand is quantised by one tmix_quantize_fp8_rows launch in front of the GEMM
+        self.fp8 = bool(fp8)
         self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
         # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
@@ -434,7 +449,9 @@ class UNetPlan:
         self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", self.B, HW, Cc))
         return out
 
-    def _gemm(self, a, w, out, **kw):
+    def _gemm(self, a, w, out, fp8_key=None, **kw):
+        if fp8_key is not None and self.fp8:
+            return self._gemm_fp8(a, fp8_key, out, **kw)
         if kw.get("row_stats_out") is not None:
             kw.setdefault("tile_cfg", 1)            # the partial count depends on the tiling: never TMIX_TILE_AUTO
         d = ops.make_gemm_desc(a, w, out, **kw)
@@ -450,6 +467,34 @@ class UNetPlan:
         self.launches["gemm"].append((d, fl))
         self._tunable.append((len(self.ops) - 1, "gemm", d))
         self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
+        return out
+
+    def _gemm_fp8(self, a, key, out, **kw):
+        """quantise the rows of `a` (one launch), then tmix_gemm_fp8 against the cached e4m3 copy of weight `key`
+        (key = (name, row_sets) for per-row LoRA weight sets)."""
+        name, rows = key if isinstance(key, tuple) else (key, None)
+        w8, sw = self.W.fp8(name, rows)
+        K = a.shape[-1]
+        a8 = self.arena.get(*a.shape, dtype=torch.uint8)
+        sa = self.arena.get(*a.shape[:-1], dtype=torch.uint8)
+        a2 = a.reshape(-1, K)
+        assert a2.data_ptr() == a.data_ptr() and a2.stride(1) == 1          # a view, rows contiguous in K
+        self._emit(self.lib.tmix_quantize_fp8_rows, a2.data_ptr(), a2.stride(0), a8.data_ptr(), K, sa.data_ptr(), a2.shape[0], K)
+        if kw.get("row_stats_out") is not None:
+            kw.setdefault("tile_cfg", 17)           # explicit (the partial count depends on it); fp8 runs the phase-offset tilings only
+        d = ops.make_gemm_desc(a8, w8, out, **kw)
+        if kw.get("row_stats_out") is not None:
+            self._ln_links.append((d, []))
+        elif kw.get("ln_stats") is not None:
+            self._ln_links[-1][1].append(d)
+        self.keep += [d, a8, sa]
+        self._emit(self.lib.tmix_gemm_fp8, C.byref(d), sa.data_ptr(), sw.data_ptr())
+        fl = 2 * d.M * d.N * d.K * d.batch
+        self.flops += fl
+        self.gemm_flops += fl
+        self.launches["gemm"].append((d, fl))
+        self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
+        self.arena.put(a8, sa)                      # stream-ordered: free for ops planned after this GEMM
         return out
 
     def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None, bias_images=1):
@@ -520,7 +565,7 @@ class UNetPlan:
             A.put(sc)
         return out
 
-    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, **kw):
+    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, fp8=False, **kw):
         """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM.
         ln: statistics of a LayerNorm folded into this projection (weights stored folded, see UNetWeights.fold);
         stats_out: accumulate the statistics of the rows this projection writes."""
@@ -536,6 +581,8 @@ class UNetPlan:
         if kw.get("residual") is not None:
             kw["residual"] = kw["residual"].view(*shp, kw["residual"].shape[-1])
         w = self._rows(key) if self.routed else W[key]
+        if fp8 and self.fp8:
+            kw["fp8_key"] = (key + "_rows", tuple(self.row_sets)) if self.routed else key
         return self._gemm(a.view(*shp, Cin), w, out.view(*shp, out.shape[-1]), **kw)
 
     def _rows(self, key, suffix=""):
@@ -563,7 +610,7 @@ class UNetPlan:
             a1, a2 = tb + ".attn1", tb + ".attn2"
             # --- self attention; norm1 is folded into the q/k/v projection
             qk = A.get(B, S, 2 * Cc)
-            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc)
+            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc, fp8=True)
             ao = A.get(B, S, Cc)
             self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
             A.put(qk)
@@ -580,9 +627,9 @@ class UNetPlan:
             # --- feed forward: norm3 folded into the first GEMM, GEGLU fused in its epilogue
             f = A.get(B * S, 4 * Cc)
             self._gemm(h.view(B * S, Cc), W[tb + ".ff1"], f, bias=W[tb + ".ff1.bias"], geglu=True,
-                       ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"])
+                       ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"], fp8_key=tb + ".ff1")
             self._gemm(f, W[tb + ".ff.net.2.weight"], h.view(B * S, Cc), bias=W[tb + ".ff.net.2.bias"], residual=h.view(B * S, Cc),
-                       row_stats_out=st if i + 1 < n else None)
+                       row_stats_out=st if i + 1 < n else None, fp8_key=tb + ".ff.net.2.weight")
             A.put(f)
         out = A.get(B, S, Cc)
         self._gemm(h.view(B * S, Cc), W[name + ".proj_out.weight"], out.view(B * S, Cc), bias=W[name + ".proj_out.bias"],
@@ -748,7 +795,7 @@ class PlanGroup:
     chain's workgroups.  Presents the same interface as a UNetPlan (latent, t_dev.fill_, eps, run, B, flops)."""
 
     def __init__(self, W: UNetWeights, h: int, w: int, ehs: torch.Tensor, wsel, pooled: torch.Tensor,
-                 time_ids: torch.Tensor, routed: bool, n_groups: int):
+                 time_ids: torch.Tensor, routed: bool, n_groups: int, fp8: bool = False):
         B = ehs.shape[0]
         assert B % n_groups == 0
         self.B, self.n_groups = B, n_groups
@@ -764,7 +811,7 @@ class PlanGroup:
             kv = KVCache(W, ehs[sl], list(wsel)[sl])
             self.plans.append(UNetPlan(W, per, h, w, kv, pooled[sl], time_ids[sl], routed=routed,
                                        row_sets=list(wsel)[sl] if routed else None,
-                                       latent=self.latent[sl], eps=self.eps[sl], shared=n_groups > 1, t_dev=self.t_dev[sl]))
+                                       latent=self.latent[sl], eps=self.eps[sl], shared=n_groups > 1, t_dev=self.t_dev[sl], fp8=fp8))
             self.streams.append(torch.cuda.Stream(device=dev) if g > 0 else None)
         self.flops = sum(p.flops for p in self.plans)
         self.gemm_flops = sum(p.gemm_flops for p in self.plans)
