@@ -79,7 +79,7 @@ def build_parser():
     p.add_argument('--gpus', type=int, default=1, help='shard the seeds over this many GPUs (one process per GPU, started by this script)')
     p.add_argument('--no_strict_reference', action='store_true',
                    help='route the concept weights for any concept count (the reference hooks only route when the UNet batch is 4, i.e. 3 concepts)')
-    p.add_argument('--streams', type=int, default=2)
+    p.add_argument('--streams', type=int, default=1, help='launch chains per UNet call (2: batch rows split over two HIP streams)')
     p.add_argument('--no_graphs', action='store_true')
     p.add_argument('--tiny', action='store_true', help='tiny UNet config (smoke tests)')
     return p

@@ -402,7 +402,7 @@ def test_bench_gpus2_self_launch_sharded_seeds(tmp_path):
     assert "all_gather" in d["trajectory"]["includes"]
 
 
-def test_cli_sharded_seeds_equal_single_process_runs(tmp_path):
+def test_cli_sharded_seeds_equal_single_process_runs(tmp_path, monkeypatch):
     """BASELINE config 4 as a command: `fusion_sampling.py --gpus 2 --num_seeds 5` (two ranks started by the script, seeds
     sharded round-robin, latents gathered, rank 0 writes the files) produces for every seed s exactly the file a
     single-process `--seed s` run writes -- bit for bit (same launch shapes, deterministic kernels)."""
@@ -415,6 +415,10 @@ def test_cli_sharded_seeds_equal_single_process_runs(tmp_path):
               "--output_path", str(tmp_path)]
     env = {k: v for k, v in _os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["TMIX_SINGLE_GPU_DIST_TEST"] = "1"
+    # the tiny config's launch shapes are not in the shipped tile table, so each process would TIME its tilings (and two processes
+    # sharing one GPU time differently): pin the tiling so that "same launch shapes" also means "same summation order"
+    env["TMIX_FORCE_TILE"] = "1"
+    monkeypatch.setenv("TMIX_FORCE_TILE", "1")
     r = subprocess.run([sys.executable, _os.path.join(root, "fusion_generation", "fusion_sampling.py"), "--gpus", "2", "--num_seeds", "5",
                         "--seeds_per_batch", "1", "--seed", "40", "--output_path_all", str(tmp_path / "sharded")] + common,
                        capture_output=True, text=True, timeout=1200, cwd=root, env=env)

@@ -251,9 +251,9 @@ def test_fp8_projections_tiny_unet_vs_oracle():
     from tweediemix_amd import unet as U
     orc, plan, x, ehs, pooled, tid = make("custom", 4, 16, 16, True)
     ref = orc.forward(x, 500, ehs, pooled, tid, routed=True)
-    base = rel_l2(plan(x.cuda(), 500).clone(), ref)
+    base = rel_l2(plan(x.cuda(), 500).clone().cpu(), ref)
     p8 = U.UNetPlan(plan.W, 4, 16, 16, plan.kv, pooled, tid, routed=True, fp8=True)
-    got = p8(x.cuda(), 500).clone()
+    got = p8(x.cuda(), 500).clone().cpu()
     r = rel_l2(got, ref)
     print(f"tiny UNet rel-L2 vs fp32 oracle: bf16 {base:.3e}, fp8 projections {r:.3e}")
     assert torch.isfinite(got).all() and base <= 2e-2 and r <= 6e-2, (base, r)

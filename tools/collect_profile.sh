@@ -5,13 +5,14 @@
 tag=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag} -- python bench.py --no-cpu-baseline > $out/bench.log 2>&1
+BARGS="--kind lora --no-trajectory --no-cpu-baseline ${BENCH_EXTRA:-}"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag} -- python bench.py $BARGS > $out/bench.log 2>&1
 grep '^{"metric' $out/bench.log > $out/${tag}_bench_line.json
 for pm in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline > $out/pmc_$pm.log 2>&1
+  rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_$pm.log 2>&1
 done
 python - $out $tag <<'PY'
-import csv, sys, json, collections
+import csv, sys, json, collections, re
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
 for pm in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -19,7 +20,8 @@ for pm in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f"{out}/{tag}_{pm}_counter_collection.csv")):
         if r["Counter_Name"] != pm: continue
         n = r["Kernel_Name"]
-        key = "gemm" if "gemm_conv_kernel" in n and ", 0>" in n else "conv" if "gemm_conv_kernel" in n else "attn" if "attn_fwd" in n else None
+        m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
+        key = ("conv" if m.group(1).split(",")[5].strip() == "1" else "gemm") if m else "attn" if ("attn_fwd" in n or "attn_small" in n) else "norm" if "gn_" in n else None
         if key:
             agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
     res[pm] = {k: {"launches": v[0], "sum_kb": v[1], "avg_kb_per_launch": v[1] / max(1, v[0])} for k, v in agg.items()}
@@ -32,7 +34,7 @@ for k in res["FETCH_SIZE"]:
 json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(summary))
 PY
-rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs --no-cpu-baseline > $out/pmc_MFMA.log 2>&1
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_MFMA.log 2>&1
 python - $out $tag <<'PY'
 import csv, sys, json, collections, re
 out, tag = sys.argv[1], sys.argv[2]
@@ -47,7 +49,7 @@ for r in csv.DictReader(open(f"{out}/{tag}_MFMA_counter_collection.csv")):
     if r["Counter_Name"] != "MfmaUtil": continue
     n = r["Kernel_Name"]
     m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
-    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "attn_fwd" if "attn_fwd" in n else None
+    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else None
     if key: agg[key].append((float(r["Counter_Value"]), dur.get(r["Dispatch_Id"], 1.0)))
 cls = collections.defaultdict(list)
 for k, v in agg.items(): cls[k.split("<")[0]] += v

@@ -16,6 +16,7 @@
 // MFMA roofline: 4*Sq*Skv*64 flops per (batch, head).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -282,6 +283,131 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
 }
 
+// ---- cross-attention against a SHORT key set (the 77 prompt tokens: diffusers attn2, utils_custom.py:93-103): K and V^T of one
+// (batch, head) are 2 x 10 KB, so every wave keeps ALL of them in registers as MFMA operands (no LDS, no barrier, no online
+// softmax: one exact maximum per query) and walks 64 queries in two blocks of 32.  The general kernel above spent 27 us per
+// launch on this shape (a 3-stage LDS ring and a barrier per 64-key tile for 1.2 tiles of work); the floor here is streaming
+// Q in and O out once.  Key slots follow the same permutation as above, so P^T feeds the PV MFMA from registers.
+constexpr int SK_MAX = 96;           // key slots (3 MFMA k-steps of 32)
+constexpr int SQW = 64;              // queries per wave
+
+__global__ void __launch_bounds__(256, 1) attn_small_kernel(const AttnParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool prof_on = p.prof != nullptr && tid == 0;
+    unsigned long long pt0 = 0, pt1 = 0;
+    if (prof_on) pt0 = prof_enter(p.prof, blockIdx.x == 0, p.prof_detail);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = bid / p.nq, qt = bid - bh * p.nq;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * (4 * SQW) + w * SQW;
+    const bf16_t* Qb = p.Q + (int64_t)b * p.strideQ + h * 64;
+    const bf16_t* Kb = p.K + (int64_t)b * p.strideK + h * 64;
+    const bf16_t* Vb = p.Vt + (int64_t)b * p.strideVt + (int64_t)h * 64 * p.ldvt;
+    bf16_t* Ob = p.O + (int64_t)b * p.strideO + h * 64;
+    const int ldvt = (int)p.ldvt;
+
+    frag_ab kf[6][2], vf[3][4];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        int key = 32 * (f >> 1) + 8 * (fr >> 2) + 4 * (f & 1) + (fr & 3); if (key > p.Skv - 1) key = p.Skv - 1;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) kf[f][ds] = *(const frag_ab*)(Kb + (int64_t)key * p.ldk + ds * 32 + fg * 8);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 3; ++ps) {
+        int c = 32 * ps + fg * 8; if (c > ldvt - 8) c = ldvt - 8;          // fully masked chunk: any finite data
+#pragma unroll
+        for (int df = 0; df < 4; ++df) vf[ps][df] = *(const frag_ab*)(Vb + (df * 16 + fr) * ldvt + c);
+    }
+    frag_ab ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    if (prof_on) pt1 = prof_now();
+
+#pragma unroll 1
+    for (int blk = 0; blk < SQW / 32; ++blk) {
+        const int qb = q0 + blk * 32;
+        if (qb >= p.Sq) break;
+        frag_ab qf[2][2];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            int q = qb + qi * 16 + fr; if (q > p.Sq - 1) q = p.Sq - 1;
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const frag_ab raw = *(const frag_ab*)(Qb + (int64_t)q * p.ldq + ds * 32 + fg * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qi][ds][j] = (__bf16)((float)raw[j] * p.scale_log2e);
+            }
+        }
+        f32x4 s[6][2];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                s[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][0], qf[qi][0], zero, 0, 0, 0);
+                s[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[f][1], qf[qi][1], s[f][qi], 0, 0, 0);
+            }
+        uint32_t pb[2][3][4];
+        f32x4 o[4][2], lacc[2];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) s[f][qi][r] = -INFINITY;
+                    m = fmaxf(m, s[f][qi][r]);
+                }
+            m = xor32_max(xor16_max(m));                               // over the 4 lane groups of this query column
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[f][qi][r] = __builtin_amdgcn_exp2f(s[f][qi][r] - m);
+#pragma unroll
+            for (int ps = 0; ps < 3; ++ps) {
+                pb[qi][ps][0] = pk_bf16(s[2 * ps][qi][0], s[2 * ps][qi][1]);
+                pb[qi][ps][1] = pk_bf16(s[2 * ps][qi][2], s[2 * ps][qi][3]);
+                pb[qi][ps][2] = pk_bf16(s[2 * ps + 1][qi][0], s[2 * ps + 1][qi][1]);
+                pb[qi][ps][3] = pk_bf16(s[2 * ps + 1][qi][2], s[2 * ps + 1][qi][3]);
+            }
+            lacc[qi] = zero;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) o[df][qi] = zero;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+            frag_ab p0, p1;
+            __builtin_memcpy(&p0, pb[0][ps], 16);
+            __builtin_memcpy(&p1, pb[1][ps], 16);
+            lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, lacc[0], 0, 0, 0);
+            lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, lacc[1], 0, 0, 0);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                o[df][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ps][df], p0, o[df][0], 0, 0, 0);
+                o[df][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ps][df], p1, o[df][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int q = qb + qi * 16 + fr;
+            if (q >= p.Sq) continue;
+            const float inv = 1.0f / lacc[qi][0];
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                uint2 v;
+                v.x = pk_bf16(o[df][qi][0] * inv, o[df][qi][1] * inv);
+                v.y = pk_bf16(o[df][qi][2] * inv, o[df][qi][3] * inv);
+                *(uint2*)(Ob + (int64_t)q * p.ldo + df * 16 + fg * 4) = v;
+            }
+        }
+    }
+    if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt1);
+}
+
 }  // namespace
 
 extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
@@ -308,6 +434,14 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.prof = tmix_prof_take(&p.prof_detail);
+    if (Skv <= SK_MAX && !getenv("TMIX_ATTN_GENERAL")) {          // short key set: K / V^T resident in registers, no LDS
+        p.nq = (Sq + 4 * SQW - 1) / (4 * SQW);
+        const int64_t nws = (int64_t)p.nq * B * H;
+        if (nws > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
+        attn_small_kernel<<<dim3((unsigned)nws), 256, 0, (hipStream_t)stream>>>(p);
+        TMIX_LAUNCH_CHECK();
+        return TMIX_OK;
+    }
     const int64_t nwg = (int64_t)p.nq * B * H;
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
     attn_fwd_kernel<<<dim3((unsigned)nwg), 256, SMEM, (hipStream_t)stream>>>(p);
