@@ -51,6 +51,8 @@ def parse(argv=None):
                     help="independent trajectories co-batched into every UNet launch (1 = the reference's one image per process)")
     ap.add_argument("--num-seeds", type=int, default=0,
                     help="BASELINE config 4: this many seeds in total, sharded round-robin over the ranks (0: seeds-per-gpu per rank)")
+    ap.add_argument("--traj-cobatch", type=int, default=4, help="independent seeds sharing every UNet launch in the images/s measurement")
+    ap.add_argument("--traj-images", type=int, default=8, help="images per rank in the images/s measurement (ignored with --num-seeds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--host-dry-run", action="store_true",
@@ -269,46 +271,72 @@ def pmc_traffic():
 # ------------------------------------------------------------------------------------------------ trajectories
 def run_trajectories(tw, args, rank, world, device):
     """whole sample_loop runs with the reference's default flags (n=50, t_cond=0.2, resampling 10, jumping 5: 75 UNet calls)
-    + the final VAE decode.  --num-seeds T: the T seeds are sharded round-robin over the ranks and co-batched
-    seeds-per-gpu at a time (BASELINE config 4); otherwise every rank runs seeds-per-gpu seeds (weak scaling)."""
-    from tweediemix_amd import dist as D, vae as V
-    S_ = tw.n_seeds
+    + the final VAE decode.  Two numbers: the latency of ONE image sampled alone (the reference's mode: one seed per process),
+    and images/s with `--traj-cobatch` independent seeds sharing every UNet launch (BASELINE config 4: a batch of seeds per GPU;
+    --num-seeds T shards T seeds round-robin over the ranks and gathers the latents, else every rank samples --traj-images)."""
+    from tweediemix_amd import dist as D, masks as M, sampler as S, vae as V
+    K = tw.concept_num
+    vcfg = V.TINY if args.tiny else V.FULL
+    vae = (vcfg, V.synthetic_state_dict(vcfg, device=device))     # random-init decoder of the SDXL VAE shapes
+
+    def noise(seed_ids, h, w):
+        return torch.cat([torch.randn(1, 4, h, w, generator=torch.Generator().manual_seed(7000 + s)) for s in seed_ids])
+
+    def sampler(n_seeds):
+        turn = [0]
+
+        def provider(x0):                   # one rectangle set per seed, in the order the sampler asks
+            turn[0] += 1
+            return M.build_masks(M.random_rectangle_masks(K, args.res, args.res, seed=31 * rank + turn[0]), tw.h, tw.w, device)
+        t = S.Tweediemix(tw.config, tw.W, tw.text_embeds, tw.text_embeds_single, provider, concept_num=K, lora=tw.lora,
+                         use_graphs=tw.use_graphs, n_seeds=n_seeds, n_streams=tw.n_streams, vae=vae, fp8=tw.fp8)
+        return t
+
+    out = {}
+    # ---- (a) one image alone
+    one = sampler(1)
+    one.run_fusion(noise([rank], tw.h, tw.w), decode=True)          # builds / captures the start, plain and VAE plans
+    n_calls = len(one.unet_calls)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    lat = one.run_fusion(noise([100 + rank], tw.h, tw.w))
+    torch.cuda.synchronize()
+    t_loop = time.perf_counter() - t1
+    img = one.decode_final(lat)
+    torch.cuda.synchronize()
+    t_img = time.perf_counter() - t1
+    assert torch.isfinite(img).all()
+    calls = one.unet_calls[n_calls:]
+    out["single_image"] = {"seconds_loop": t_loop, "seconds_incl_vae_decode": t_img, "unet_calls": len(calls),
+                           "calls_BK1": sum(1 for c in calls if c[1] == K + 1), "calls_B2": sum(1 for c in calls if c[1] == 2)}
+    del one
+    torch.cuda.empty_cache()
+    # ---- (b) throughput: co-batched seeds
+    C_ = max(1, args.traj_cobatch)
     if args.num_seeds:
         mine = D.seed_shard(list(range(args.num_seeds)), rank, world)
         total = args.num_seeds
     else:
-        mine = [rank * S_ + i for i in range(S_)]
-        total = world * S_
-    vcfg = V.TINY if args.tiny else V.FULL
-    tw.vae = (vcfg, V.synthetic_state_dict(vcfg, device=device))     # random-init decoder of the SDXL VAE shapes
-
-    def noise(seed_ids):
-        xs = [torch.randn(1, 4, tw.h, tw.w, generator=torch.Generator().manual_seed(7000 + s)) for s in seed_ids]
-        return torch.cat(xs)
-
-    batches = [mine[i:i + S_] for i in range(0, len(mine), S_)]
-    tw.unet_calls.clear()
-    warm = tw.run_fusion(noise((batches[0] + batches[0] * S_)[:S_]) if batches else noise(list(range(S_))), decode=True)
+        mine = [rank * args.traj_images + i for i in range(args.traj_images)]
+        total = world * args.traj_images
+    co = sampler(C_)
+    batches = [mine[i:i + C_] for i in range(0, len(mine), C_)]
+    warm = co.run_fusion(noise(((batches[0] if batches else [0]) * C_)[:C_], tw.h, tw.w), decode=True)
     assert torch.isfinite(warm).all()
-    n_calls = len(tw.unet_calls)
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
     t1 = time.perf_counter()
-    lats, t_loop = [], 0.0
+    lats = []
     for b in batches:
-        ids = (b + b * S_)[:S_]                       # a ragged last batch is padded with repeats and trimmed afterwards
-        tl = time.perf_counter()
-        lat = tw.run_fusion(noise(ids))
-        torch.cuda.synchronize()
-        t_loop += time.perf_counter() - tl
-        img = tw.decode_final(lat)
-        assert torch.isfinite(img).all()
+        ids = (b + b * C_)[:C_]                       # a ragged last batch is padded with repeats and trimmed afterwards
+        lat = co.run_fusion(noise(ids, tw.h, tw.w))
+        img = co.decode_final(lat)
         lats.append(lat[:len(b)])
     local = torch.cat(lats) if lats else torch.zeros(0, 4, tw.h, tw.w, device=device)
     torch.cuda.synchronize()
-    gathered = local
+    assert torch.isfinite(local).all()
     if world > 1 and args.num_seeds:                   # the result gather: the only collective of the path
         gathered = D.gather_latents(local.contiguous(), total, rank, world)
         assert gathered.shape[0] == total and torch.isfinite(gathered).all()
@@ -316,16 +344,14 @@ def run_trajectories(tw, args, rank, world, device):
     dt = time.perf_counter() - t1
     if world > 1:
         dt = D.max_over_ranks(dt, device)
-    n_local = len(mine)
-    calls = tw.unet_calls[n_calls:]
-    K = tw.concept_num
-    return {"images": total, "seconds": dt, "images_per_s": total / dt if dt > 0 else 0.0,
-            "rank0_seconds_per_image_loop_only": t_loop / max(1, n_local), "rank0_images": n_local,
-            "unet_calls_per_image": len(calls) // max(1, len(batches)),
-            "calls_BK1": sum(1 for c in calls if c[1] == K + 1) // max(1, len(batches)),
-            "calls_B2": sum(1 for c in calls if c[1] == 2) // max(1, len(batches)),
-            "includes": "50-step sample_loop (start + 10 resampling repeats, plain, 5 jumping look-ahead steps, fusion) + final VAE decode"
-                        + (" + RCCL all_gather of the latents" if world > 1 and args.num_seeds else "")}
+    del co
+    torch.cuda.empty_cache()
+    out.update({"images": total, "seconds": dt, "images_per_s": total / dt if dt > 0 else 0.0, "cobatch": C_,
+                "images_per_rank": len(mine),
+                "includes": f"50-step sample_loop (start + 10 resampling repeats, plain, 5 jumping look-ahead steps, fusion) + final VAE "
+                            f"decode, {C_} independent seeds per UNet launch"
+                            + (" + RCCL all_gather of the latents" if world > 1 and args.num_seeds else "")})
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline

@@ -221,6 +221,7 @@ class I2VPlan(UNetPlan):
         self.flops = self.gemm_flops = 0
         self.launches = {"gemm": [], "conv": [], "attn": []}
         self.op_meta = {}
+        self.fp8 = False                                 # (the fp8 projections are wired for the image UNet only)
         self._tunable, self._ln_links, self._vt = [], [], {}
         self.kv = _KV(W, context, frames)
         self.x_in = torch.zeros(B, 2 * cfg.in_channels, h, w, device=dev, dtype=F32)
