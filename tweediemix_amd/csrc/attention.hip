@@ -23,13 +23,12 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
-constexpr int QB = 128;          // query rows per workgroup (32 per wave)
+constexpr int QB = 128;          // query rows per 4-wave workgroup (32 per wave); the 8-wave form covers 256
 constexpr int KB = 64;           // keys per tile
 constexpr int TILE = KB * 64 * 2;    // 8 KiB (K tile or V^T tile)
 constexpr int STAGE = 2 * TILE;
 constexpr int NS = 3;                // LDS ring depth: NS-1 tiles requested ahead, NS-2 in flight across a barrier
 constexpr int SMEM = NS * STAGE;     // 48 KiB -> 3 workgroups per CU
-constexpr int LOADS = 4;             // LDS-DMA instructions per wave per tile
 
 struct AttnParams {
     const bf16_t* Q; int64_t ldq, strideQ;
@@ -72,7 +71,13 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     return *(uint32_t*)&v;
 }
 
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
+// NWV = 4 (default): 128 query rows per workgroup, two workgroups per CU.  NWV = 8: 256 rows, ONE workgroup per CU -- the same
+// eight waves per CU, a K / V^T tile staged once for 256 queries instead of twice for 2 x 128 (half the LDS-DMA instructions
+// per wave, half the L2 -> LDS traffic) -- but slower in situ, see tmix_attn_fwd.
+template <int NWV>
+__global__ void __launch_bounds__(NWV * 64, 2) attn_fwd_kernel(const AttnParams p) {
+    constexpr int LOADS = 16 / NWV;      // LDS-DMA instructions per wave per tile (16 KiB tile, 1 KiB per instruction)
+    constexpr int NR = 8 / NWV;          // staging rounds per wave and operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = bid / p.nq, qt = bid - bh * p.nq;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qt * QB + w * 32;
+    const int q0 = qt * (NWV * 32) + w * 32;
 
     const bf16_t* Qb = p.Q + (int64_t)b * p.strideQ + h * 64;
     const bf16_t* Kb = p.K + (int64_t)b * p.strideK + h * 64;
@@ -107,11 +112,11 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     // ---- staging geometry: per wave 2 rounds x (8 rows x 8 chunks) for K and for V^T
     const int lrow = lane >> 3;
     const int schunk = ((lane & 7) ^ lrow) * 8;
-    int krow[2];                       // key (within tile) whose row lands in this lane's LDS row
-    int vrow[2];                       // d row of V^T
+    int krow[NR];                      // key (within tile) whose row lands in this lane's LDS row
+    int vrow[NR];                      // d row of V^T
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int rho = (r * 4 + w) * 8 + lrow;            // LDS row 0..63
+    for (int r = 0; r < NR; ++r) {
+        const int rho = (r * NWV + w) * 8 + lrow;          // LDS row 0..63
         const int f = rho >> 4, i = rho & 15;
         krow[r] = 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3);
         vrow[r] = rho;
@@ -119,17 +124,17 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnParams p) {
     const int nt = (p.Skv + KB - 1) / KB;
     // per-lane source offsets stay 32-bit (elements); the 64-bit bases are wave-uniform
     const int ldk = (int)p.ldk, ldvt = (int)p.ldvt;
-    int voff[2];
+    int voff[NR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) voff[r] = vrow[r] * ldvt;
+    for (int r = 0; r < NR; ++r) voff[r] = vrow[r] * ldvt;
     auto stage = [&](int buf, int t) {
         char* sK = smem + buf * STAGE;
         char* sV = sK + TILE;
         const int kv0 = t * KB;
         int c = kv0 + schunk; if (c > ldvt - 8) c = ldvt - 8;       // fully masked chunk: any finite data
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int off = (r * 4 + w) * 1024;
+        for (int r = 0; r < NR; ++r) {
+            const int off = (r * NWV + w) * 1024;
             int key = kv0 + krow[r]; if (key > p.Skv - 1) key = p.Skv - 1;
             glds16(Kb + (unsigned)(key * ldk + schunk), sK + off);
             glds16(Vb + (unsigned)(voff[r] + c), sV + off);
@@ -422,7 +427,8 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     if (!aligned16(Q) || !aligned16(K) || !aligned16(Vt) || (((uintptr_t)O) & 7)) TMIX_FAIL(TMIX_EALIGN, "attn: pointer alignment");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -442,9 +448,16 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
         TMIX_LAUNCH_CHECK();
         return TMIX_OK;
     }
+    // the 8-wave form (256-row workgroups) measured SLOWER in situ (S = 1024: 48.2 vs 37.8 us, S = 4096: 267 vs 221): one barrier
+    // over eight waves per tile costs more than the halved LDS-DMA issue saves, and two independent 4-wave workgroups per CU drift
+    // apart so that one's softmax overlaps the other's MFMAs.  Kept for experiments: TMIX_ATTN_WAVES=8.
+    const char* fw = getenv("TMIX_ATTN_WAVES");
+    const bool eight = fw && atoi(fw) == 8;
+    if (eight) p.nq = (Sq + 255) / 256;
     const int64_t nwg = (int64_t)p.nq * B * H;
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
-    attn_fwd_kernel<<<dim3((unsigned)nwg), 256, SMEM, (hipStream_t)stream>>>(p);
+    if (eight) attn_fwd_kernel<8><<<dim3((unsigned)nwg), 512, SMEM, (hipStream_t)stream>>>(p);
+    else       attn_fwd_kernel<4><<<dim3((unsigned)nwg), 256, SMEM, (hipStream_t)stream>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
