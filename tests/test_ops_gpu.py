@@ -188,7 +188,7 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
                                    (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
 def test_gemm_plain(ops, M, N, K, cfg):
@@ -197,7 +197,7 @@ def test_gemm_plain(ops, M, N, K, cfg):
     close(out, a.float() @ w.float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
@@ -209,7 +209,7 @@ def test_gemm_epilogues(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
@@ -223,7 +223,7 @@ def test_gemm_geglu(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     Bz, M, C = 3, 100, 128
     a = rnd(Bz, M, C, seed=11)
@@ -239,6 +239,61 @@ def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     big = rnd(Bz, M, 2 * C, seed=13)
     out = ops.gemm(big[:, :, C:], w[0])
     close(out, big[:, :, C:].float() @ w[0].float().T)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17])
+def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch):
+    """the LDS-staged 16-byte stores (default) against the accumulator-layout 8-byte stores (TMIX_NARROW_EPILOGUE=1, the
+    fallback for unaligned rows): same values, same operation order per element => identical C, GEGLU output and V^T; the
+    row statistics are summed in a different (fixed) order, so they agree to fp32 rounding only."""
+    M, N, K = 520, 640, 256                                   # M not a tile multiple: edge rows on both paths
+    a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+    bias, res = rnd(N, seed=5, dtype=torch.float32), rnd(M, N, seed=6)
+    rgb = rnd(5, N, seed=7, dtype=torch.float32)
+    a3, w3 = rnd(2, 264, K, seed=8), rnd(2, 768, K, seed=9, scale=K ** -0.5)
+    from tweediemix_amd.weights import interleave_geglu
+    wi, bi = interleave_geglu(rnd(1024, K, seed=10, scale=K ** -0.5), rnd(1024, seed=11, dtype=torch.float32))
+
+    def run():
+        st = torch.zeros(ops.stats_parts(N, cfg), M, 2, device="cuda")
+        c = ops.gemm(a, w, bias=bias, residual=res, rowgroup_bias=rgb, rows_per_group=104, tile_cfg=cfg)
+        c2 = ops.gemm(a, w, bias=bias, residual=res, row_stats_out=st, tile_cfg=cfg)
+        g = ops.gemm(a, wi, bias=bi, geglu=True, tile_cfg=cfg)
+        vt = torch.zeros(2, 256, 264, device="cuda", dtype=BF)
+        qk = ops.gemm(a3, w3, out_t=vt, n_trans_begin=512, tile_cfg=cfg)
+        f32 = torch.zeros(M, N, device="cuda")
+        ops.gemm(a, w, out=None, out_f32=f32, tile_cfg=cfg)
+        torch.cuda.synchronize()
+        return c, c2, g, vt, qk, f32, st
+    wide = run()
+    monkeypatch.setenv("TMIX_NARROW_EPILOGUE", "1")
+    narrow = run()
+    for x, y, name in zip(wide[:6], narrow[:6], ("C", "C+stats", "GEGLU", "Vt", "QK", "f32")):
+        assert torch.equal(x, y), name
+    torch.testing.assert_close(wide[6], narrow[6], rtol=1e-5, atol=1e-4)
+    s = wide[6].sum(0)                                        # and the statistics are those of the stored rows
+    torch.testing.assert_close(s[:, 0], wide[1].float().sum(1), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(s[:, 1], (wide[1].float() ** 2).sum(1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 1, 64, 1), (2, 3, 1000, 77), (1, 2, 70, 96), (2, 2, 300, 33), (1, 20, 1024, 77)])
+def test_short_key_attention_kernel_matches_the_general_one(ops, B, H, Sq, Skv, monkeypatch):
+    """attn_small_kernel (K / V^T register-resident, exact softmax; Skv <= 96) vs torch and vs the tiled flash kernel
+    (TMIX_ATTN_GENERAL=1) on the same inputs, incl. ragged query counts and a single key."""
+    Cc = H * 64
+    q, k, v = rnd(B, Sq, Cc, seed=50), rnd(B, Skv, Cc, seed=51), rnd(B, Skv, Cc, seed=52)
+    ld = (Skv + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, ld, device="cuda", dtype=BF)
+    vt[:, :, :Skv] = v.transpose(1, 2)
+    small = ops.attention(q, k, vt, H, Skv, 0.125)
+    monkeypatch.setenv("TMIX_ATTN_GENERAL", "1")
+    general = ops.attention(q, k, vt, H, Skv, 0.125)
+
+    def heads(t):
+        return t.float().reshape(B, -1, H, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(heads(q), heads(k), heads(v), scale=0.125).transpose(1, 2).reshape(B, Sq, Cc)
+    close(small, ref, rtol=2 ** -6, atol_frac=4e-3)
+    close(small, general.float(), rtol=2 ** -6, atol_frac=4e-3)
 
 
 def test_gemm_rejects_bad_shapes(ops):
