@@ -115,7 +115,8 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_32x160_W5 = 15 /* five waves of 32x32: 1024 x 1280 (one batch row per chain) is 256 tiles */,
        TMIX_TILE_256x256_PH = 16 /* eight waves, K slices of 32 through a four-slot ring, the second wave of each SIMD one barrier behind the first */,
        TMIX_TILE_256x128_PH = 17,
-       TMIX_TILE_COUNT = 17 };
+       TMIX_TILE_128x160_S4_K2 = 18 /* tiling 12 with in-workgroup split-K: two groups of four waves share the tile (eight waves stage) */,
+       TMIX_TILE_COUNT = 18 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

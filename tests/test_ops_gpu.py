@@ -188,7 +188,7 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
                                    (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
 def test_gemm_plain(ops, M, N, K, cfg):
@@ -197,7 +197,7 @@ def test_gemm_plain(ops, M, N, K, cfg):
     close(out, a.float() @ w.float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
@@ -209,7 +209,7 @@ def test_gemm_epilogues(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
@@ -223,7 +223,7 @@ def test_gemm_geglu(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     Bz, M, C = 3, 100, 128
     a = rnd(Bz, M, C, seed=11)
@@ -241,7 +241,7 @@ def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     close(out, big[:, :, C:].float() @ w[0].float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17, 18])
 def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch):
     """the LDS-staged 16-byte stores (default) against the accumulator-layout 8-byte stores (TMIX_NARROW_EPILOGUE=1, the
     fallback for unaligned rows): same values, same operation order per element => identical C, GEGLU output and V^T; the

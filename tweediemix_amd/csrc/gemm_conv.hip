@@ -22,7 +22,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         tmix_gemm_tile_shape(cfg, &bm, &bn);
         if (p.n_trans_begin % bn) cfg = 2;                                     // the boundary must fall on a tile edge (N = 3 x 320: 640)
         if (!(p.wide & 4)) {                                                   // narrow (unstaged) transposed stores need square wave tiles
-            if (cfg == 4 || cfg == 5 || cfg == 7 || cfg >= 12) cfg = 2;
+            if (cfg == 4 || cfg == 5 || cfg == 7 || cfg >= 12) cfg = 2;      // (18 included)
             if (cfg == 8 || cfg == 11) cfg = 9;
         }
     }
@@ -38,6 +38,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         else if (cfg == 17 || cfg == 9) cfg = 2;
         else if (cfg == 8) cfg = 7;
         else if (cfg == 10) cfg = 1;
+        else if (cfg == 18) cfg = 12;
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
     int rc = launch_group0(cfg, conv, f8, p, batch, st);
     if (rc == -999) rc = launch_group1(cfg, conv, f8, p, batch, st);
@@ -53,7 +54,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
                                               {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160},
-                                              {256, 256}, {256, 128}};
+                                              {256, 256}, {256, 128}, {128, 160}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

@@ -75,12 +75,18 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // raised priority).  The second wave of every SIMD (waves 4-7) runs one barrier behind the first, so on each SIMD one wave
 // issues DMA / ds_read while its partner keeps the matrix pipe busy -- an LDS-DMA instruction blocks its OWN wave's issue
 // for ~100 cycles (tools/ubench/dma_issue), which is what held the lock-step loop below at ~50 % of the MFMA rate.
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0>
+// KS = 2 (in-workgroup split-K): a SECOND group of WM x WN waves shares the tile; both groups stage (eight waves issue the
+// LDS-DMA of a K-tile instead of four), group g multiplies k-steps 2g, 2g+1 of every 64-deep K-tile into its own accumulators,
+// and after the loop group 1 hands its partial tile to group 0 through the (now free) staging ring.  For this path's
+// one-tile-per-CU launches (4096 x 1280: 256 tiles of 128 x 160) the K loop is bound by how fast a CU can pull operands
+// L2 -> LDS, and that rate grows with the number of waves issuing DMA (measured 38 GB/s per CU with four, 52 with eight).
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 // (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
-__global__ void __launch_bounds__((WM * WN + LW) * 64, LW ? 3 : (WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
+__global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? 3 : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
 gemm_conv_kernel(const Params p) {
     static_assert(!PH || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
+    static_assert(KS == 1 || (KS == 2 && !LW && !PH && !CONV), "in-workgroup split-K geometry");
     // PH = 2: the same loop on OCP fp8 (e4m3) operands: a slice row is still 64 bytes, i.e. 64 K values, and the eight
     // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
     // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
@@ -93,7 +99,7 @@ gemm_conv_kernel(const Params p) {
     constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
     constexpr int SLOT = (BM + BN) * 64;               // PH: one 32-wide K slice of both operands (rows of 64 bytes)
     constexpr int RING = PH ? 4 * SLOT : NS * STAGE;   // bytes of the staging ring (the fused-LayerNorm block sits behind it)
-    constexpr int SW = LW ? 1 : NW;                    // waves that share the staging of a K-tile
+    constexpr int SW = LW ? 1 : NW * KS;               // waves that share the staging of a K-tile
     constexpr int IA = BM / 8, IB = BN / 8;            // LDS-DMA instructions per stage (8 rows of 128 bytes each)
     // ... per staging wave; when the waves do not divide them (64x160 over 5 waves) a surplus slot re-stages the last rows
     // (same bytes to the same place), so every wave issues the same count and the counted vmcnt waits stay valid
@@ -106,7 +112,9 @@ gemm_conv_kernel(const Params p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w / WN, wc = w - wr * WN;
+    const int kg = KS > 1 ? w / NW : 0;                // split-K group of this wave
+    const int wm_ = KS > 1 ? w - kg * NW : w;          // position among the group's math waves
+    const int wr = wm_ / WN, wc = wm_ - wr * WN;
     const bool prof_on = p.prof != nullptr && tid == 0;
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
     if (prof_on) pt0 = prof_enter(p.prof, (blockIdx.x | blockIdx.y) == 0, p.prof_detail);
@@ -360,14 +368,16 @@ gemm_conv_kernel(const Params p) {
         const char* pb = smem + buf * STAGE + off_b;
         // fragments of k-step kk+1 are requested before the MFMAs of k-step kk issue (register double buffer)
         frag_ab a[2][FM], b[2][FN];
+        constexpr int KPW = 4 / KS;                    // k-steps of this wave's split-K group
+        const int k0 = kg * KPW;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[0][i] = *(const frag_ab*)(pa + i * 32 * 128 + ((lhi ^ fsw) << 4));
+        for (int i = 0; i < FM; ++i) a[0][i] = *(const frag_ab*)(pa + i * 32 * 128 + (((k0 * 2 + lhi) ^ fsw) << 4));
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + ((lhi ^ fsw) << 4));
+        for (int j = 0; j < FN; ++j) b[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + (((k0 * 2 + lhi) ^ fsw) << 4));
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
-                const int sw = (((kk + 1) * 2 + lhi) ^ fsw) << 4;
+        for (int kk = 0; kk < KPW; ++kk) {
+            if (kk < KPW - 1) {
+                const int sw = (((k0 + kk + 1) * 2 + lhi) ^ fsw) << 4;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) a[(kk + 1) & 1][i] = *(const frag_ab*)(pa + i * 32 * 128 + sw);
 #pragma unroll
@@ -470,11 +480,11 @@ gemm_conv_kernel(const Params p) {
             __builtin_amdgcn_s_setprio(1);
             char* sA = smem + ((s + 3) & 3) * SLOT;
             char* sW = sA + BM * 64;
-            constexpr int KS = F8 ? 1 : 2;                          // MFMA k-steps per slice
-            constexpr int NMF = KS * FM * FN, GAP = NMF / PL;       // one DMA after every GAP-th MFMA
+            constexpr int KSTEPS = F8 ? 1 : 2;                      // MFMA k-steps per slice
+            constexpr int NMF = KSTEPS * FM * FN, GAP = NMF / PL;       // one DMA after every GAP-th MFMA
             int issued = 0;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
+            for (int kk = 0; kk < KSTEPS; ++kk)
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -539,6 +549,36 @@ gemm_conv_kernel(const Params p) {
     }
     }
 
+    if constexpr (KS > 1) {
+        // split-K hand-over: group 1 parks its partial tile in the staging ring (every wave has passed the loop's last barrier,
+        // the ring is free), lane-linear 16-byte pieces at the position its group-0 twin (same wave tile) reads them from
+        float4* xch = (float4*)smem + (size_t)wm_ * (FM * FN * 4 * 64) + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        xch[((i * FN + j) * 4 + g) * 64] = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        }
+        __syncthreads();
+        if (kg == 1) {                                 // done; keep the workgroup's barrier count (as the loader waves do)
+            __syncthreads();                           // group 0 has read the partials
+            if (p.stats_out) __syncthreads();          // the epilogue's row-statistics exchange
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = xch[((i * FN + j) * 4 + g) * 64];
+                    acc[i][j][g * 4] += v.x; acc[i][j][g * 4 + 1] += v.y; acc[i][j][g * 4 + 2] += v.z; acc[i][j][g * 4 + 3] += v.w;
+                }
+        __syncthreads();                               // the patches of the staged epilogue reuse this memory
+    }
     if (prof_on) pt2 = prof_now();
     // ---------------------------------------------------------------- fused LayerNorm (consumer side), part 2
     // A was the raw row x; with W' = W*gamma:  Linear(LN(x))[m][n] = rstd_m * (acc[m][n] - mean_m * colsum_n) + t_n
@@ -998,13 +1038,15 @@ struct TileCfg { int bm, bn; };
 // (a 5-deep ring for 13 measured the same as the 4-deep one)
 // 16 = 256x256, 17 = 256x128 with the PHASE-OFFSET mainloop (PH: eight waves, K slices of 32 through a four-slot ring, the
 // second wave of every SIMD one barrier behind the first; GEMM only, no transposed region)
-constexpr int NUM_CFG = 17;
+// 18 = tiling 12 (128x160, 4-deep ring) with in-workgroup split-K over two wave groups (KS = 2): eight waves stage, GEMM only
+constexpr int NUM_CFG = 18;
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0>
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
+    static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
     constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
     static bool attr_set = false;   // idempotent; racing threads set the same value
-    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH>;
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1015,7 +1057,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     if (BM >= 256 && BN >= 256) p.group_m = 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     p.prof = tmix_prof_take(&p.prof_detail);
-    kern<<<grid, (WM * WN + LW) * 64, SMEM, st>>>(p);
+    kern<<<grid, (WM * WN * KS + LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
