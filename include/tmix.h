@@ -153,7 +153,14 @@ int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
  * when strideW != 0).  v_mfma_scale_f32_32x32x64_f8f6f4 applies both scales in hardware (per-row instead of the MX format's
  * per-32 blocks, so a lane keeps its scales for the whole K loop); accumulation and every epilogue of tmix_gemm_bf16 (bias,
  * fused LayerNorm on A, GEGLU, residual, transposed V, row statistics) are unchanged.  tile_cfg: TMIX_TILE_AUTO,
- * TMIX_TILE_256x256_PH or TMIX_TILE_256x128_PH. */
+ * TMIX_TILE_256x256_PH or TMIX_TILE_256x128_PH.
+ * Two flags in tmix_gemm_desc.reserved0 chain fp8 GEMMs without a quantiser pass in between (FF up-projection -> down-projection):
+ *   TMIX_F8_GEGLU_OUT       with TMIX_EPI_GEGLU: C receives e4m3 BYTES [M][N/2] (ldc in bytes) and Ct (ldct >= batch*M) the E8M0 scales of
+ *                           every 32 output columns, k-block major: Ct[(col / 32) * ldct + b*M + m] -- the MX block form;
+ *   TMIX_F8_A_BLOCK_SCALES  scale_a is such a block-scale array [K/32][batch*M] instead of one byte per row (the instruction applies
+ *                           a lane's scale to exactly its 32 K values); scale_w stays per row.  The K/32 blocks of a tile stay in
+ *                           LDS for the whole K loop: K <= 7168 (256x256 tiles up to K = 2816, 256x128 beyond), M %% 4 == 0. */
+enum { TMIX_F8_A_BLOCK_SCALES = 1, TMIX_F8_GEGLU_OUT = 2 };
 int tmix_gemm_fp8(const tmix_gemm_desc* d, const uint8_t* scale_a, const uint8_t* scale_w, void* stream);
 /* Row quantiser for tmix_gemm_fp8: X bf16 [rows][ld] -> Q e4m3 [rows][ldq] and scale_e8m0[r] = the smallest exponent that brings
  * max|X[r]| under 448 (K %% 8 == 0, K <= 8192).  Used on activations before each fp8 GEMM and once on the weights. */

@@ -588,3 +588,82 @@ def test_gemm_fp8_equals_fp32_product_of_the_dequantized_operands(ops, tile, M, 
     err = float((out.float() - (exact + (res.float() if res is not None else 0))).norm() / exact.norm())
     print(f"fp8 GEMM {M}x{N}x{K}: rel-L2 vs the unquantised bf16 product = {err:.3e}")
     assert err < 6e-2
+
+
+def _mx_quantize(x):
+    """torch reference of the MX block form: x fp32 [rows, K] -> (e4m3 bytes [rows, K], E8M0 scales [K/32, rows])."""
+    rows, K = x.shape
+    xb = x.view(rows, K // 32, 32)
+    amax = xb.abs().amax(dim=2)
+    e = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)).float(), torch.zeros_like(amax))
+    q = (xb * torch.exp2(-e).unsqueeze(2)).to(torch.float8_e4m3fn).view(torch.uint8).view(rows, K)
+    return q.contiguous(), (e + 127).to(torch.uint8).t().contiguous(), (q.view(torch.float8_e4m3fn).float().view(rows, K // 32, 32)
+                                                                        * torch.exp2(e).unsqueeze(2)).view(rows, K)
+
+
+@pytest.mark.parametrize("tile", [16, 17])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1024, 1280, 5120), (300, 264, 128)])
+def test_gemm_fp8_with_mx_block_scales_on_a(ops, tile, M, N, K):
+    """TMIX_F8_A_BLOCK_SCALES: one E8M0 scale per 32 K values of every A row, kept in LDS for the K loop (lane half h of a 64-wide
+    slice s applies scale [2 s + h]) -- against the fp32 product of the dequantised operands."""
+    a = rnd(M, K, seed=1, dtype=torch.float32)
+    a[:, 64:96] *= 37.0                                    # blocks of very different magnitude in one row
+    a[5] = 0
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    a8, sa, ad = _mx_quantize(a)
+    w8, sw = ops.quantize_fp8_rows(w)
+    wd = ops.dequantize_fp8_rows(w8, sw)
+    bias = torch.randn(N, device="cuda")
+    res = rnd(M, N, seed=3)
+    out = ops.gemm_fp8(a8, sa, w8, sw, bias=bias, residual=res, tile_cfg=tile, a_block_scales=True)
+    close(out, ad @ wd.t() + bias + res.float())
+
+
+def test_gemm_fp8_mx_block_scales_batched_and_limits(ops):
+    """Batched launches index the scale array [K/32][batch * M] at column b * M + m; K beyond what the tile can keep in LDS beside
+    the staging ring, and rows that break the 4-byte pieces of the scale copy, are refused (no silent fallback)."""
+    B, M, N, K = 2, 264, 256, 192
+    a = rnd(B * M, K, seed=4, dtype=torch.float32)
+    a[:, 32:64] *= 19.0
+    w = rnd(B, N, K, seed=5, scale=K ** -0.5)
+    a8, sa, ad = _mx_quantize(a)
+    w8, sw = ops.quantize_fp8_rows(w.view(B * N, K))
+    wd = ops.dequantize_fp8_rows(w8, sw).view(B, N, K)
+    out = ops.gemm_fp8(a8.view(B, M, K), sa, w8.view(B, N, K), sw.view(B, N), tile_cfg=17, a_block_scales=True)
+    close(out, torch.einsum("bmk,bnk->bmn", ad.view(B, M, K), wd))
+    from tweediemix_amd.lib import TmixError
+    K2 = 32 * 256
+    with pytest.raises(TmixError):
+        ops.gemm_fp8(torch.zeros(64, K2, device="cuda", dtype=torch.uint8), torch.zeros(K2 // 32, 64, device="cuda", dtype=torch.uint8),
+                     torch.zeros(64, K2, device="cuda", dtype=torch.uint8), torch.zeros(64, device="cuda", dtype=torch.uint8), a_block_scales=True)
+    with pytest.raises(TmixError):
+        ops.gemm_fp8(torch.zeros(66, 64, device="cuda", dtype=torch.uint8), torch.zeros(2, 66, device="cuda", dtype=torch.uint8),
+                     torch.zeros(64, 64, device="cuda", dtype=torch.uint8), torch.zeros(64, device="cuda", dtype=torch.uint8), a_block_scales=True)
+
+
+@pytest.mark.parametrize("tile", [16, 17])
+def test_gemm_fp8_geglu_output_as_mx_blocks_feeds_the_next_gemm(ops, tile):
+    """TMIX_F8_GEGLU_OUT: the FF up-projection writes value * gelu(gate) as e4m3 with one scale per 32 output columns, exactly
+    what a quantiser would produce from the bf16 result, and the down-projection consumes it (A block scales): FF1 -> FF2 without a
+    quantiser pass and with half the bytes of the bf16 intermediate."""
+    from tweediemix_amd.weights import interleave_geglu
+    M, C = 520, 256
+    a = rnd(M, C, seed=8)
+    w1, b1 = rnd(8 * C, C, seed=9, scale=C ** -0.5), rnd(8 * C, seed=10, dtype=torch.float32)
+    wi, bi = interleave_geglu(w1, b1)
+    a8, sa = ops.quantize_fp8_rows(a)
+    wi8, swi = ops.quantize_fp8_rows(wi.contiguous())
+    ref_bf16 = ops.gemm_fp8(a8, sa, wi8, swi, bias=bi, geglu=True, tile_cfg=tile)          # the bf16 form of the same GEMM
+    c8 = torch.zeros(M, 4 * C, device="cuda", dtype=torch.uint8)
+    cs = torch.zeros(4 * C // 32, M, device="cuda", dtype=torch.uint8)
+    ops.gemm_fp8(a8, sa, wi8, swi, bias=bi, geglu=True, tile_cfg=tile, f8_out=(c8, cs))
+    torch.cuda.synchronize()
+    q, s, deq = _mx_quantize(ref_bf16.float())
+    assert torch.equal(cs, s)
+    same = (c8 == q) | (((c8 & 0x7f) == 0) & ((q & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+    # and the chain: FF2 on the e4m3 intermediate
+    w2 = rnd(C, 4 * C, seed=11, scale=(4 * C) ** -0.5)
+    w28, sw2 = ops.quantize_fp8_rows(w2)
+    out = ops.gemm_fp8(c8, cs, w28, sw2, tile_cfg=tile, a_block_scales=True)
+    close(out, deq @ ops.dequantize_fp8_rows(w28, sw2).t())

@@ -39,6 +39,15 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// smallest E8M0 exponent e (value 2^e, stored as e + 127) with amax * 2^-e <= 448, the e4m3 maximum; 0 for an all-zero block
+__device__ __forceinline__ int e8m0_for_amax(float amax) {
+    if (!(amax > 0.f)) return 0;
+    const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
+    int e = (int)((bits >> 23) & 0xff) - 127 + ((bits & 0x7fffff) ? 1 : 0);
+    return e < -127 ? -127 : (e > 127 ? 127 : e);
+}
+__device__ __forceinline__ float exp2_neg_int(int e) { return __uint_as_float((unsigned)(127 - e) << 23); }      // 2^-e, e in [-127, 127]
+
 // thread-local error string (host side)
 void tmix_set_error(const char* fmt, ...);
 #define TMIX_FAIL(code, ...) do { tmix_set_error(__VA_ARGS__); return (code); } while (0)

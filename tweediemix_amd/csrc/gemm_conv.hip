@@ -28,8 +28,9 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     }
     int f8 = 0;
     if (!conv && p.scaleA) {     // fp8 operands (tmix_gemm_fp8): the phase-offset loop only; 256x128 tiles for narrow N
-        f8 = 1;
+        f8 = p.ldScaleA ? 2 : 1;
         cfg = (cfg == 17 || (cfg != 16 && (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch < 160)) ? 17 : 16;
+        if (f8 == 2 && cfg == 16 && p.K / 32 > f8_block_cap(256)) cfg = 17;    // the tile's block scales stay in LDS beside the ring
     }
     if (conv) {
         // the phase-offset and loader-wave mainloops exist for the plain GEMM only (the im2col gather's per-row offset tables do
@@ -104,7 +105,18 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     if (fp8) {
         if (d->tile_cfg != TMIX_TILE_AUTO && d->tile_cfg != 16 && d->tile_cfg != 17) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg must be AUTO, 16 (256x256) or 17 (256x128)");
         p.scaleA = scaleA; p.scaleW = scaleW; p.strideScaleA = d->strideA ? d->M : 0; p.strideScaleW = d->strideW ? d->N : 0;
-    }
+        if (d->reserved0 & TMIX_F8_A_BLOCK_SCALES) {
+            p.ldScaleA = (int64_t)d->batch * d->M;                                                // [K/32][batch * M], dense
+            if ((d->M % 4) || (((uintptr_t)scaleA) & 3)) TMIX_FAIL(TMIX_EALIGN, "gemm_fp8: block-scaled A needs M %% 4 == 0 and a 4-byte aligned scale array");
+            if (d->K / 32 > f8_block_cap(128)) TMIX_FAIL(TMIX_ESHAPE, "gemm_fp8: block-scaled A supports K <= %d", 32 * f8_block_cap(128));
+            if ((int64_t)(d->K / 32) * p.ldScaleA >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm_fp8: block scale array exceeds 32-bit offsets");
+        }
+        if (d->reserved0 & TMIX_F8_GEGLU_OUT) {
+            if (d->epilogue != TMIX_EPI_GEGLU || !d->Ct || d->ldct < (int64_t)d->batch * d->M || (d->ldc % 8) || (d->strideC % 8) || (((uintptr_t)d->C) & 7))
+                TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: e4m3 GEGLU output needs the GEGLU epilogue, Ct = scale buffer [N/64][ldct >= batch*M] and 8-byte aligned C rows");
+            p.f8out = 1; p.scale_out = (unsigned char*)d->Ct; p.ldScaleOut = d->ldct;
+        }
+    } else if (d->reserved0) TMIX_FAIL(TMIX_EINVAL, "gemm: the fp8 flags in reserved0 belong to tmix_gemm_fp8");
     if (d->row_stats_out && (has_trans || d->epilogue != TMIX_EPI_NONE)) TMIX_FAIL(TMIX_EINVAL, "gemm: row_stats_out needs the plain bf16 epilogue");
     if (d->row_stats_out && (d->tile_cfg < 1 || d->tile_cfg > NUM_CFG || (((uintptr_t)d->row_stats_out) & 7) || (d->strideStatsOut & 1) || d->ldStatsOut < d->M))
         TMIX_FAIL(TMIX_EINVAL, "gemm: row_stats_out needs an explicit tile_cfg (its partial count depends on it) and 8-byte alignment");
@@ -118,11 +130,12 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     const bool r16 = !d->residual || (aligned16(d->residual) && (d->ldr % 8) == 0 && (d->strideR % 8) == 0);
     p.wide = 0;
     if (!getenv("TMIX_NARROW_EPILOGUE")) {
-        if (d->epilogue == TMIX_EPI_GEGLU) { if (c16) p.wide |= 2; }
+        if (d->epilogue == TMIX_EPI_GEGLU) { if (c16 || p.f8out) p.wide |= 2; }
         else if (d->epilogue == TMIX_EPI_F32OUT) { if (aligned16(d->C) && (d->ldc % 4) == 0 && (d->strideC % 4) == 0 && (d->N % 8) == 0) p.wide |= 1; }
         else if (c16 && r16 && (d->N % 8) == 0) p.wide |= 1;
         if (has_trans && aligned16(d->Ct) && (d->ldct % 8) == 0 && (d->strideCt % 8) == 0) p.wide |= 4;
     }
+    if (p.f8out && !(p.wide & 2)) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: e4m3 GEGLU output needs the staged epilogue");
     if (fp8 && has_trans && !(p.wide & 4)) TMIX_FAIL(TMIX_EALIGN, "gemm_fp8: the transposed region needs a 16-byte aligned Ct with ldct %% 8 == 0");
     return launch(0, p, d->batch, d->tile_cfg, (hipStream_t)stream);
 }

@@ -52,6 +52,8 @@ struct Params {
     unsigned long long* prof; int prof_detail;   // in-situ timing slot (common.h) or NULL
     int wide;                         // bit 0 / 1 / 2: the C / GEGLU / Ct stores may use the LDS-staged 16-byte form
     const unsigned char* scaleA; const unsigned char* scaleW; int64_t strideScaleA, strideScaleW;   // fp8: E8M0 exponent per A row / W row
+    int64_t ldScaleA;                 // fp8 with MX block scales on A (PH = 3): scaleA is [K/32][ldScaleA] (k-block major)
+    unsigned char* scale_out; int64_t ldScaleOut; int f8out;    // GEGLU output as e4m3 bytes + [N/64][ldScaleOut] block scales
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -60,6 +62,9 @@ struct Params {
 static __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
+
+// MX block scales of A (PH = 3) live in LDS for the whole K loop: the K/32 blocks of a launch must fit beside the staging ring
+constexpr int f8_block_cap(int bn) { return bn >= 256 ? 88 : 224; }
 
 template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -91,7 +96,8 @@ gemm_conv_kernel(const Params p) {
     // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
     // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
     // scales once and the K assignment inside a 64-byte slice need only be the same for both operands.
-    constexpr bool F8 = PH == 2;
+    constexpr bool F8 = PH >= 2;
+    constexpr bool F8B = PH == 3;                      // A carries one scale per 32 K values (MX blocks), streamed with the slices
     constexpr int EB = F8 ? 1 : 2;                     // bytes per operand element
     constexpr int NW = WM * WN;                        // math waves
     constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
@@ -422,9 +428,24 @@ gemm_conv_kernel(const Params p) {
             const unsigned char* sa = p.scaleA + (int64_t)bz * p.strideScaleA;
             const unsigned char* sw = p.scaleW + (int64_t)bz * p.strideScaleW;
 #pragma unroll
-            for (int i = 0; i < FM; ++i) f8sA[i] = (int)(sa[min(m0 + wr * TM + i * 32 + l31, p.M - 1)] * 0x01010101u);
+            for (int i = 0; i < FM; ++i) f8sA[i] = F8B ? 0 : (int)(sa[min(m0 + wr * TM + i * 32 + l31, p.M - 1)] * 0x01010101u);
 #pragma unroll
             for (int j = 0; j < FN; ++j) f8sW[j] = (int)(sw[min(n0 + wc * TN + j * 32 + l31, p.N - 1)] * 0x01010101u);
+        }
+        // F8B: the tile's A scales -- bytes [k-block][row], K/32 <= SCB blocks -- are copied into LDS behind the fused-LayerNorm block by
+        // 1 KB LDS-DMA pieces queued AHEAD of the prologue's operand pieces (so the prologue's counted wait retires them too); a lane
+        // then reads byte [2 s + half][its row] in the LOAD segment of slice s.  (Streaming them through registers with
+        // global_load_ubyte one slice ahead was tried first: the compiler copies loop-carried registers at the back edge, i.e.
+        // while such a load is still in flight -- nothing it can see orders that copy behind the counted wait.)
+        char* const scl = smem + RING + (BM + BN) * 16 + BM * 4;
+        if constexpr (F8B) {
+            const int nblk = p.K / 32;
+            const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)p.scaleA, 0, (int)((int64_t)nblk * p.ldScaleA), 0x00020000);
+            const unsigned lane_off = (unsigned)((lane * 16) / BM) * (unsigned)p.ldScaleA + (unsigned)((lane * 16) % BM)
+                                    + (unsigned)(bz * p.strideScaleA + m0);
+            const int npcs = (nblk * BM + 1023) / 1024;
+            for (int q = w; q < npcs; q += NW)
+                blds16(rsS, lane_off + (unsigned)(q * (1024 / BM)) * (unsigned)p.ldScaleA, 0u, scl + q * 1024);
         }
         const int f4 = (lane >> 2) & 3;                // (row >> 2) & 3 of fragment row base + (lane & 31)
         const int q0 = ((0 + lhi) ^ f4) << 4, q1 = ((2 + lhi) ^ f4) << 4;      // k-step 0 / 1 of the slice
@@ -450,8 +471,12 @@ gemm_conv_kernel(const Params p) {
             const char* pw = smem + (s & 3) * SLOT + offW4;
             frag_ab a[2][FM], b[2][FN];
             v8i_t a8[F8 ? FM : 1], b8[F8 ? FN : 1];
-            if constexpr (F8) {                       // lane (row, half): bytes [32 * half, 32 * half + 32) of the row's 64-byte slice
-                const int c0 = ((2 * lhi) ^ f4) << 4, c1 = ((2 * lhi + 1) ^ f4) << 4;
+            int f8use[F8B ? FM : 1];
+            if constexpr (F8) {
+                // operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 (probed, tools/probe_mx.py): lane (row, half h) holds K values
+                // [16 h, 16 h + 16) in its first 16 bytes and [32 + 16 h, 32 + 16 h + 16) in its second; the scale supplied by
+                // lane half b covers K block [32 b, 32 b + 32) -- i.e. the first / second 16 bytes of BOTH halves
+                const int c0 = (lhi ^ f4) << 4, c1 = ((2 + lhi) ^ f4) << 4;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const uint4 lo = *(const uint4*)(pa + i * 32 * 64 + c0), hi = *(const uint4*)(pa + i * 32 * 64 + c1);
@@ -470,6 +495,11 @@ gemm_conv_kernel(const Params p) {
             }
             // slice s + 1 must have landed (for every wave) before the barrier in front of its first reader; in flight
             // here: slices s + 1 and s + 2 (slice s + 3 is issued below)
+            if constexpr (F8B) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)                 // the E8M0 byte goes to all four byte lanes of the scale operand
+                    f8use[i] = (int)((unsigned)(unsigned char)scl[(2 * s + lhi) * BM + wr * TM + i * 32 + l31] * 0x01010101u);
+            }
             if (s + 2 < ns) wait_vmcnt<PL>(); else wait_vmcnt<0>();
             if (PREF && s == ns - 1 && Rb && plain_epi) prefetch_residual();     // rides under the last MFMA segment
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -489,7 +519,7 @@ gemm_conv_kernel(const Params p) {
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
-                        if constexpr (F8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, f8sW[j], 0, f8sA[i]);
+                        if constexpr (F8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, f8sW[j], 0, F8B ? f8use[i] : f8sA[i]);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
                         const int idx = (kk * FM + i) * FN + j;
                         if constexpr (ST) {
@@ -768,8 +798,29 @@ gemm_conv_kernel(const Params p) {
                     const int r = ps * RPI + rr, m = m0 + wr * TM + i * 32 + r;
                     const uint4 v = *(const uint4*)(stg + r * SR + cc * 2);
                     const int nb = n0 + wc * TN + (j0 + cc / 16) * 32;              // weight row of the fragment this lane's columns come from
+                    const int col = (n0 + wc * TN) / 2 + j0 * 16 + cc;              // output column of this lane's 8 values
+                    if constexpr (CF >= 2) {
+                        if (p.f8out) {
+                            // e4m3 output with one E8M0 scale per 32 columns (the MX block of the GEMM that reads it): the block is the
+                            // 4 adjacent lanes of this row
+                            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                            float f[8], am = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(u[k] << 16); f[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
+                                                          am = fmaxf(am, fmaxf(fabsf(f[2 * k]), fabsf(f[2 * k + 1]))); }
+                            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2));
+                            const int e = e8m0_for_amax(am);
+                            const float inv = exp2_neg_int(e);
+                            int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
+                            int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, q1, true);
+                            if (m >= p.M || nb >= p.N) continue;
+                            *(uint2*)((unsigned char*)p.C + (int64_t)bz * p.strideC + (int64_t)m * p.ldc + col) = make_uint2((unsigned)q0, (unsigned)q1);
+                            if ((lane & 3) == 0) p.scale_out[(int64_t)(col >> 5) * p.ldScaleOut + (int64_t)bz * p.M + m] = (unsigned char)(e + 127);
+                            continue;
+                        }
+                    }
                     if (m >= p.M || nb >= p.N) continue;
-                    *(uint4*)(Cb + (int64_t)m * p.ldc + (n0 + wc * TN) / 2 + j0 * 16 + cc) = v;
+                    *(uint4*)(Cb + (int64_t)m * p.ldc + col) = v;
                 }
             };
 #pragma unroll
@@ -1044,7 +1095,9 @@ constexpr int NUM_CFG = 18;
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
-    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4;     // staging ring + fused-LayerNorm block
+    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4      // staging ring + fused-LayerNorm block
+                       + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
+    static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
     auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS>;
     if (!attr_set) {

@@ -522,16 +522,8 @@ __global__ void __launch_bounds__(256) quantize_fp8_rows_kernel(const bf16_t* __
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-    // smallest e with amax * 2^-e <= 448:  e = ceil(log2(amax / 448)); exact through the exponent / mantissa of amax / 448
-    int e = 0;
-    if (amax > 0.f) {
-        const float q = amax * (1.0f / 448.0f);
-        const unsigned bits = __float_as_uint(q);
-        e = (int)((bits >> 23) & 0xff) - 127 + ((bits & 0x7fffff) ? 1 : 0);
-        if (e < -127) e = -127;
-        if (e > 127) e = 127;
-    }
-    const float inv = __uint_as_float((unsigned)(127 - e) << 23);       // 2^-e (e in [-127, 127] -> a normal or zero-exponent float)
+    const int e = e8m0_for_amax(amax);
+    const float inv = exp2_neg_int(e);
     if (lane == 0) scale[r] = (unsigned char)(e + 127);
 #pragma unroll
     for (int u = 0; u < MAXV; ++u) {

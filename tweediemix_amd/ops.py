@@ -163,16 +163,31 @@ def dequantize_fp8_rows(q, scale):
     return q.view(torch.float8_e4m3fn).float() * torch.exp2(scale.float() - 127.0).unsqueeze(-1)
 
 
-def gemm_fp8(a8, sa, w8, sw, out=None, **kw):
-    """gemm() on e4m3 operands with per-row E8M0 scales (tmix_gemm_fp8): a8 [.., M, K] uint8 + sa [.., M]; w8 [.., N, K] + sw [.., N]."""
+def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, **kw):
+    """gemm() on e4m3 operands with per-row E8M0 scales (tmix_gemm_fp8): a8 [.., M, K] uint8 + sa [.., M]; w8 [.., N, K] + sw [.., N].
+    a_block_scales: sa is the MX block form [K/32, rows] (k-block major) instead.
+    f8_out=(c8 uint8 [.., M, N/2], scales uint8 [N/64, rows]) with geglu=True: the GEGLU result leaves as e4m3 + block scales."""
     _need_cuda(a8, w8, sa, sw)
     lib = L.load()
+    if f8_out is not None:
+        c8, cs = f8_out
+        assert kw.get("geglu") and c8.dtype == torch.uint8 and cs.dtype == torch.uint8 and cs.is_contiguous() and c8.stride(-1) == 1
+        d = make_gemm_desc(a8, w8, None, **kw)
+        c3 = c8 if c8.dim() == 3 else c8.unsqueeze(0)
+        d.C, d.ldc, d.strideC = c3.data_ptr(), c3.stride(1), (c3.stride(0) if c3.shape[0] > 1 else 0)
+        d.Ct, d.ldct = cs.data_ptr(), cs.shape[1]
+        d.reserved0 = L.F8_GEGLU_OUT | (L.F8_A_BLOCK_SCALES if a_block_scales else 0)
+        L.check(lib.tmix_gemm_fp8(C.byref(d), sa.data_ptr(), sw.data_ptr(), _stream()), "tmix_gemm_fp8")
+        return c8, cs
     if out is None and kw.get("out_f32") is None:
         N = w8.shape[-2]
         No = N // 2 if kw.get("geglu") else (kw["n_trans_begin"] if kw.get("out_t") is not None else N)
         out = torch.empty(*a8.shape[:-1], No, device=a8.device, dtype=BF16)
     assert sa.dtype == torch.uint8 and sw.dtype == torch.uint8 and sa.is_contiguous() and sw.is_contiguous()
     d = make_gemm_desc(a8, w8, out, **kw)
+    if a_block_scales:
+        assert sa.dim() == 2 and sa.shape[0] == a8.shape[-1] // 32
+        d.reserved0 = L.F8_A_BLOCK_SCALES
     L.check(lib.tmix_gemm_fp8(C.byref(d), sa.data_ptr(), sw.data_ptr(), _stream()), "tmix_gemm_fp8")
     return out if out is not None else kw.get("out_f32")
 
