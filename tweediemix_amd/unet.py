@@ -326,6 +326,7 @@ class UNetPlan:
         # fp8: the attn1 q/k/v, FF up- and down-projections run as tmix_gemm_fp8 (e4m3 operands, per-row power-of-two scales);
         # their A operand is quantised by one tmix_quantize_fp8_rows launch in front of the GEMM
         self.fp8 = bool(fp8)
+        self.fp8_chain_ff = not os.environ.get("TMIX_FP8_FF_ROWS")    # =1: quantise the FF intermediate per row with a separate launch
         self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
         # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
@@ -469,20 +470,36 @@ class UNetPlan:
         self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
         return out
 
-    def _gemm_fp8(self, a, key, out, **kw):
-        """quantise the rows of `a` (one launch), then tmix_gemm_fp8 against the cached e4m3 copy of weight `key`
-        (key = (name, row_sets) for per-row LoRA weight sets)."""
+    def _gemm_fp8(self, a, key, out, f8_out=None, **kw):
+        """tmix_gemm_fp8 against the cached e4m3 copy of weight `key` (key = (name, row_sets) for per-row LoRA weight sets).
+        a: bf16 rows -- quantised by one tmix_quantize_fp8_rows launch in front of the GEMM -- or a pair (e4m3 bytes, MX block
+        scales [K/32][rows]) as left by a GEMM planned with f8_out=(bytes [M][N/2], scales [N/64][M]) (GEGLU epilogue only):
+        FF1 -> FF2 without a quantiser pass and with half the bytes of the bf16 intermediate."""
         name, rows = key if isinstance(key, tuple) else (key, None)
         w8, sw = self.W.fp8(name, rows)
-        K = a.shape[-1]
-        a8 = self.arena.get(*a.shape, dtype=torch.uint8)
-        sa = self.arena.get(*a.shape[:-1], dtype=torch.uint8)
-        a2 = a.reshape(-1, K)
-        assert a2.data_ptr() == a.data_ptr() and a2.stride(1) == 1          # a view, rows contiguous in K
-        self._emit(self.lib.tmix_quantize_fp8_rows, a2.data_ptr(), a2.stride(0), a8.data_ptr(), K, sa.data_ptr(), a2.shape[0], K)
+        flags = 0
+        if isinstance(a, tuple):
+            a8, sa = a
+            flags |= L.F8_A_BLOCK_SCALES
+            owned = ()
+        else:
+            K = a.shape[-1]
+            a8 = self.arena.get(*a.shape, dtype=torch.uint8)
+            sa = self.arena.get(*a.shape[:-1], dtype=torch.uint8)
+            a2 = a.reshape(-1, K)
+            assert a2.data_ptr() == a.data_ptr() and a2.stride(1) == 1          # a view, rows contiguous in K
+            self._emit(self.lib.tmix_quantize_fp8_rows, a2.data_ptr(), a2.stride(0), a8.data_ptr(), K, sa.data_ptr(), a2.shape[0], K)
+            owned = (a8, sa)
         if kw.get("row_stats_out") is not None:
             kw.setdefault("tile_cfg", 17)           # explicit (the partial count depends on it); fp8 runs the phase-offset tilings only
-        d = ops.make_gemm_desc(a8, w8, out, **kw)
+        d = ops.make_gemm_desc(a8, w8, None if f8_out is not None else out, **kw)
+        if f8_out is not None:
+            c8, cs = f8_out
+            assert kw.get("geglu") and c8.dim() == 2 and c8.stride(1) == 1 and cs.is_contiguous()
+            d.C, d.ldc, d.strideC = c8.data_ptr(), c8.stride(0), 0
+            d.Ct, d.ldct = cs.data_ptr(), cs.shape[1]
+            flags |= L.F8_GEGLU_OUT
+        d.reserved0 = flags
         if kw.get("row_stats_out") is not None:
             self._ln_links.append((d, []))
         elif kw.get("ln_stats") is not None:
@@ -494,7 +511,8 @@ class UNetPlan:
         self.gemm_flops += fl
         self.launches["gemm"].append((d, fl))
         self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
-        self.arena.put(a8, sa)                      # stream-ordered: free for ops planned after this GEMM
+        if owned:
+            self.arena.put(*owned)                  # stream-ordered: free for ops planned after this GEMM
         return out
 
     def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None, bias_images=1):
@@ -625,6 +643,16 @@ class UNetPlan:
             self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st)
             A.put(ao)
             # --- feed forward: norm3 folded into the first GEMM, GEGLU fused in its epilogue
+            if self.fp8 and self.fp8_chain_ff:
+                # the intermediate leaves FF1 as e4m3 with one E8M0 scale per 32 columns and FF2 reads it as block-scaled A
+                f = A.get(B * S, 4 * Cc, dtype=torch.uint8)
+                fs = A.get(4 * Cc // 32, B * S, dtype=torch.uint8)
+                self._gemm_fp8(h.view(B * S, Cc), tb + ".ff1", None, f8_out=(f, fs), bias=W[tb + ".ff1.bias"], geglu=True,
+                               ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"])
+                self._gemm_fp8((f, fs), tb + ".ff.net.2.weight", h.view(B * S, Cc), bias=W[tb + ".ff.net.2.bias"],
+                               residual=h.view(B * S, Cc), row_stats_out=st if i + 1 < n else None)
+                A.put(f, fs)
+                continue
             f = A.get(B * S, 4 * Cc)
             self._gemm(h.view(B * S, Cc), W[tb + ".ff1"], f, bias=W[tb + ".ff1.bias"], geglu=True,
                        ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"], fp8_key=tb + ".ff1")
