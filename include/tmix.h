@@ -258,6 +258,11 @@ int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float sh
  * act: 0 none, 1 SiLU.  add (nullable): fp32 [M,N] added before act_out. */
 int tmix_linear_small(const float* in, const void* W, const float* bias, const float* add, float* out,
                       int M, int N, int K, int act_in, int act_out, void* stream);
+/* The same for several weight matrices stacked along N that share the input (every ResnetBlock2D's time_emb_proj of one UNet
+ * forward: 19 launches -> 1): sec_starts is a DEVICE array of nsec + 1 ascending column offsets (sec_starts[0] = 0,
+ * sec_starts[nsec] = N); section s leaves as its own dense fp32 [M][width_s] matrix at out + sec_starts[s] * M. */
+int tmix_linear_small_sections(const float* in, const void* W, const float* bias, float* out, int M, int N, int K,
+                               int act_in, const int* sec_starts, int nsec, void* stream);
 
 #ifdef __cplusplus
 }

@@ -406,6 +406,22 @@ def test_groupnorm(ops, B, HW, C1, C2, silu):
     close(y, ref.transpose(1, 2))
 
 
+def test_linear_small_sections_matches_separate_launches(ops):
+    """tmix_linear_small_sections: stacked weight matrices sharing the input, each section leaving as its own dense [M, width]."""
+    M, K = 4, 1280
+    widths = [320, 640, 1280, 320]
+    x = torch.randn(M, K, device="cuda")
+    ws = [rnd(n, K, seed=70 + i, scale=K ** -0.5) for i, n in enumerate(widths)]
+    bs = [rnd(n, seed=80 + i, dtype=torch.float32) for i, n in enumerate(widths)]
+    st = torch.tensor([0] + list(torch.tensor(widths).cumsum(0)), device="cuda", dtype=torch.int32)
+    flat = ops.linear_small_sections(x, torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), st, act_in=True)
+    off = 0
+    for w, b_ in zip(ws, bs):
+        n = w.shape[0]
+        assert torch.equal(flat[off * M:(off + n) * M].view(M, n), ops.linear_small(x, w, b_, act_in=True))
+        off += n
+
+
 @pytest.mark.parametrize("rows,Cc", [(77, 640), (1024, 1280), (5, 64), (3, 2048)])
 def test_layernorm(ops, rows, Cc):
     x = rnd(rows, Cc, seed=54) * 3 + 1

@@ -312,7 +312,8 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ values, floa
 template <int MAXM>
 __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ in, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ add,
-                                                           float* __restrict__ out, int M, int N, int K, int act_in, int act_out) {
+                                                           float* __restrict__ out, int M, int N, int K, int act_in, int act_out,
+                                                           const int* __restrict__ secs, int nsec) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -344,10 +345,17 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
         for (int o = 32; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o);
     }
     if (lane == 0) {
+        // sections: columns [secs[s], secs[s+1]) leave as their own dense [M][width] matrix at out + secs[s] * M
+        int64_t base = 0; int ldn = N, col = n;
+        if (secs) {
+            int sidx = 0;
+            while (sidx + 1 < nsec && secs[sidx + 1] <= n) ++sidx;
+            base = (int64_t)secs[sidx] * M; ldn = secs[sidx + 1] - secs[sidx]; col = n - secs[sidx];
+        }
         for (int m = 0; m < M; ++m) {
             float y = acc[m] + (bias ? bias[n] : 0.f) + (add ? add[(int64_t)m * N + n] : 0.f);
             if (act_out) y = silu_f(y);
-            out[(int64_t)m * N + n] = y;
+            out[base + (int64_t)m * ldn + col] = y;
         }
     }
 }
@@ -711,8 +719,20 @@ extern "C" int tmix_linear_small(const float* in, const void* W, const float* bi
     if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 8)) TMIX_FAIL(TMIX_ESHAPE, "linear_small: M=%d (1..16) N=%d K=%d (K %% 8 == 0)", M, N, K);
     if (!aligned16(in) || !aligned16(W)) TMIX_FAIL(TMIX_EALIGN, "linear_small: in/W must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (M <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out);
-    else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out);
+    if (M <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out, nullptr, 0);
+    else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out, nullptr, 0);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_linear_small_sections(const float* in, const void* W, const float* bias, float* out, int M, int N, int K,
+                                          int act_in, const int* sec_starts, int nsec, void* stream) {
+    if (!in || !W || !out || !sec_starts) TMIX_FAIL(TMIX_EINVAL, "linear_small_sections: null pointer");
+    if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 8) || nsec < 1) TMIX_FAIL(TMIX_ESHAPE, "linear_small_sections: M=%d (1..16) N=%d K=%d (K %% 8 == 0) nsec=%d", M, N, K, nsec);
+    if (!aligned16(in) || !aligned16(W)) TMIX_FAIL(TMIX_EALIGN, "linear_small_sections: in/W must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, nullptr, out, M, N, K, act_in, 0, sec_starts, nsec);
+    else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, nullptr, out, M, N, K, act_in, 0, sec_starts, nsec);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }

@@ -87,6 +87,7 @@ SIGNATURES = {
     "tmix_concat_channels": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, i64, vp]),
     "tmix_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "tmix_linear_small": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tmix_linear_small_sections": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
 }
 
 _lib = None

@@ -320,6 +320,22 @@ def timestep_embedding(values, dim, out=None):
     return out
 
 
+def linear_small_sections(x, w, bias, sec_starts, act_in=False, out=None):
+    """x [M<=16,K] fp32 against weight matrices stacked along N (w [N,K] bf16, sec_starts int32 device [nsec+1]):
+    returns the flat fp32 buffer whose slice [sec_starts[s]*M, sec_starts[s+1]*M) is section s as a dense [M, width_s] matrix."""
+    _need_cuda(x, w, sec_starts)
+    lib = L.load()
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype == BF16 and w.is_contiguous() and w.shape[1] == K
+    assert sec_starts.dtype == torch.int32 and sec_starts.is_contiguous()
+    if out is None:
+        out = torch.empty(M * N, device=x.device, dtype=torch.float32)
+    L.check(lib.tmix_linear_small_sections(_p(x), _p(w), _p(bias), _p(out), M, N, K, int(bool(act_in)), _p(sec_starts),
+                                           sec_starts.numel() - 1, _stream()), "tmix_linear_small_sections")
+    return out
+
+
 def linear_small(x, w, bias=None, add=None, act_in=False, act_out=False, out=None):
     """x [M<=16,K] fp32, w [N,K] bf16 -> [M,N] fp32."""
     _need_cuda(x, w)

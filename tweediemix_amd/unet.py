@@ -119,6 +119,7 @@ class UNetWeights:
         self.kind = concepts[0] if concepts else "none"
         self.K = len(concepts[1]) if concepts else 0
         self._fp8 = {}
+        self._tproj = None
         dev = self.device
         t = {}
 
@@ -197,6 +198,19 @@ class UNetWeights:
 
     def __getitem__(self, k):
         return self.t[k]
+
+    def stacked_time_proj(self):
+        """(weight [sum Co, T] bf16, bias [sum Co] fp32, section starts int32 [n+1] on the device, resnet names) of all
+        `<resnet>.time_emb_proj` layers (diffusers ResnetBlock2D.time_emb_proj), stacked once."""
+        if self._tproj is None:
+            names = sorted(k[:-len(".time_emb_proj.weight")] for k in self.t if k.endswith(".time_emb_proj.weight"))
+            w = torch.cat([self[n + ".time_emb_proj.weight"] for n in names], 0).contiguous()
+            b = torch.cat([self[n + ".time_emb_proj.bias"].float() for n in names], 0).contiguous()
+            st = [0]
+            for n in names:
+                st.append(st[-1] + self[n + ".time_emb_proj.weight"].shape[0])
+            self._tproj = (w, b, torch.tensor(st, device=w.device, dtype=torch.int32), names)
+        return self._tproj
 
     def fp8(self, key, rows=None):
         """(e4m3 bytes, E8M0 row scales) of weight `key` ([N,K], or the [R,N,K] stack gathered by `rows`), quantised once per
@@ -564,10 +578,8 @@ class UNetPlan:
         B, W, A = self.B, self.W, self.arena
         HW = Hh * Ww
         h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True)
-        temb = torch.empty(B, Co, device=self.dev, dtype=F32)
-        self.keep.append(temb)
-        self._emit(self.lib.tmix_linear_small, emb.data_ptr(), W[name + ".time_emb_proj.weight"].data_ptr(),
-                   W[name + ".time_emb_proj.bias"].data_ptr(), None, temb.data_ptr(), B, Co, self.cfg.time_embed_dim, 1, 0)
+        temb = self._temb[name]                     # [B, Co] fp32: this block's section of the one stacked time_emb_proj launch
+        assert temb.shape == (B, Co)
         h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb)
         A.put(h1)
         h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
@@ -687,6 +699,14 @@ class UNetPlan:
                    W["time_embedding.linear_1.bias"].data_ptr(), None, thid.data_ptr(), B, T, C0, 0, 1)
         self._emit(lib.tmix_linear_small, thid.data_ptr(), W["time_embedding.linear_2.weight"].data_ptr(),
                    W["time_embedding.linear_2.bias"].data_ptr(), self.aug.data_ptr(), emb.data_ptr(), B, T, T, 0, 0)
+        # every ResnetBlock2D's time_emb_proj(SiLU(emb)) in ONE launch: the weights are stacked along N once per checkpoint
+        tw, tb_, starts, names = W.stacked_time_proj()
+        tall = torch.empty(B * tw.shape[0], device=self.dev, dtype=F32)
+        self.keep.append(tall)
+        self._emit(lib.tmix_linear_small_sections, emb.data_ptr(), tw.data_ptr(), tb_.data_ptr(), tall.data_ptr(), B, tw.shape[0], T, 1,
+                   starts.data_ptr(), len(names))
+        hs = starts.tolist()
+        self._temb = {n: tall[hs[i] * B:hs[i + 1] * B].view(B, hs[i + 1] - hs[i]) for i, n in enumerate(names)}
         Hh, Ww = self.h, self.w
         x = A.get(B, Hh * Ww, C0)
         self._emit(lib.tmix_conv_in, self.latent.data_ptr(), W["conv_in.weight"].data_ptr(), W["conv_in.bias"].data_ptr(),
