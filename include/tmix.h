@@ -254,7 +254,7 @@ int tmix_temporal_attn(const void* QKV, int64_t ld, void* O, int64_t ldo, int cl
                        float scale, void* stream);
 /* y = clamp(x*scale + shift, lo, hi) on fp32 (image post-processing (img/2+0.5).clamp(0,1), fusion_sampling.py:302) */
 int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
-/* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 16.
+/* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 256 (16 rows per launch).
  * act: 0 none, 1 SiLU.  add (nullable): fp32 [M,N] added before act_out. */
 int tmix_linear_small(const float* in, const void* W, const float* bias, const float* add, float* out,
                       int M, int N, int K, int act_in, int act_out, void* stream);

@@ -406,9 +406,11 @@ def test_groupnorm(ops, B, HW, C1, C2, silu):
     close(y, ref.transpose(1, 2))
 
 
-def test_linear_small_sections_matches_separate_launches(ops):
-    """tmix_linear_small_sections: stacked weight matrices sharing the input, each section leaving as its own dense [M, width]."""
-    M, K = 4, 1280
+@pytest.mark.parametrize("M", [4, 16, 37])
+def test_linear_small_sections_matches_separate_launches(ops, M):
+    """tmix_linear_small_sections: stacked weight matrices sharing the input, each section leaving as its own dense [M, width]
+    (M > 16: co-batched seeds, rows go out 16 per launch)."""
+    K = 1280
     widths = [320, 640, 1280, 320]
     x = torch.randn(M, K, device="cuda")
     ws = [rnd(n, K, seed=70 + i, scale=K ** -0.5) for i, n in enumerate(widths)]
@@ -418,7 +420,9 @@ def test_linear_small_sections_matches_separate_launches(ops):
     off = 0
     for w, b_ in zip(ws, bs):
         n = w.shape[0]
-        assert torch.equal(flat[off * M:(off + n) * M].view(M, n), ops.linear_small(x, w, b_, act_in=True))
+        sep = ops.linear_small(x, w, b_, act_in=True)
+        assert torch.equal(flat[off * M:(off + n) * M].view(M, n), sep)
+        close(sep, F.silu(x) @ w.float().t() + b_)
         off += n
 
 

@@ -313,7 +313,7 @@ template <int MAXM>
 __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ in, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ add,
                                                            float* __restrict__ out, int M, int N, int K, int act_in, int act_out,
-                                                           const int* __restrict__ secs, int nsec) {
+                                                           const int* __restrict__ secs, int nsec, int Mtot, int mrow0) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -350,12 +350,12 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
         if (secs) {
             int sidx = 0;
             while (sidx + 1 < nsec && secs[sidx + 1] <= n) ++sidx;
-            base = (int64_t)secs[sidx] * M; ldn = secs[sidx + 1] - secs[sidx]; col = n - secs[sidx];
+            base = (int64_t)secs[sidx] * Mtot; ldn = secs[sidx + 1] - secs[sidx]; col = n - secs[sidx];
         }
         for (int m = 0; m < M; ++m) {
             float y = acc[m] + (bias ? bias[n] : 0.f) + (add ? add[(int64_t)m * N + n] : 0.f);
             if (act_out) y = silu_f(y);
-            out[base + (int64_t)m * ldn + col] = y;
+            out[base + (int64_t)(secs ? mrow0 + m : m) * ldn + col] = y;
         }
     }
 }
@@ -713,28 +713,37 @@ extern "C" int tmix_timestep_embedding(const float* values, float* out, int coun
     return TMIX_OK;
 }
 
+// rows beyond 16 go out in further launches of 16 (co-batched seeds: B = 32 rows of time / text embeddings)
+static int linear_small_launch(const float* in, const void* W, const float* bias, const float* add, float* out, int M, int N, int K,
+                               int act_in, int act_out, const int* secs, int nsec, hipStream_t st) {
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        const int m = M - m0 < 16 ? M - m0 : 16;
+        const float* in_c = in + (int64_t)m0 * K;
+        const float* add_c = add ? add + (int64_t)m0 * N : nullptr;
+        // sections: every section is a dense [M][width] matrix, so a row chunk starts m0 * width into each -- the kernel adds
+        // secs[s] * M itself; the plain form is one [M][N] matrix
+        float* out_c = secs ? out : out + (int64_t)m0 * N;
+        if (m <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in_c, (const bf16_t*)W, bias, add_c, out_c, m, N, K, act_in, act_out, secs, nsec, M, m0);
+        else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in_c, (const bf16_t*)W, bias, add_c, out_c, m, N, K, act_in, act_out, secs, nsec, M, m0);
+        TMIX_LAUNCH_CHECK();
+    }
+    return TMIX_OK;
+}
+
 extern "C" int tmix_linear_small(const float* in, const void* W, const float* bias, const float* add, float* out,
                                  int M, int N, int K, int act_in, int act_out, void* stream) {
     if (!in || !W || !out) TMIX_FAIL(TMIX_EINVAL, "linear_small: null pointer");
-    if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 8)) TMIX_FAIL(TMIX_ESHAPE, "linear_small: M=%d (1..16) N=%d K=%d (K %% 8 == 0)", M, N, K);
+    if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % 8)) TMIX_FAIL(TMIX_ESHAPE, "linear_small: M=%d (1..256) N=%d K=%d (K %% 8 == 0)", M, N, K);
     if (!aligned16(in) || !aligned16(W)) TMIX_FAIL(TMIX_EALIGN, "linear_small: in/W must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    if (M <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out, nullptr, 0);
-    else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, add, out, M, N, K, act_in, act_out, nullptr, 0);
-    TMIX_LAUNCH_CHECK();
-    return TMIX_OK;
+    return linear_small_launch(in, W, bias, add, out, M, N, K, act_in, act_out, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int tmix_linear_small_sections(const float* in, const void* W, const float* bias, float* out, int M, int N, int K,
                                           int act_in, const int* sec_starts, int nsec, void* stream) {
     if (!in || !W || !out || !sec_starts) TMIX_FAIL(TMIX_EINVAL, "linear_small_sections: null pointer");
-    if (M <= 0 || M > 16 || N <= 0 || K <= 0 || (K % 8) || nsec < 1) TMIX_FAIL(TMIX_ESHAPE, "linear_small_sections: M=%d (1..16) N=%d K=%d (K %% 8 == 0) nsec=%d", M, N, K, nsec);
+    if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (K % 8) || nsec < 1) TMIX_FAIL(TMIX_ESHAPE, "linear_small_sections: M=%d (1..256) N=%d K=%d (K %% 8 == 0) nsec=%d", M, N, K, nsec);
     if (!aligned16(in) || !aligned16(W)) TMIX_FAIL(TMIX_EALIGN, "linear_small_sections: in/W must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    if (M <= 4) linear_small_kernel<4><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, nullptr, out, M, N, K, act_in, 0, sec_starts, nsec);
-    else        linear_small_kernel<16><<<(N + 3) / 4, 256, 0, st>>>(in, (const bf16_t*)W, bias, nullptr, out, M, N, K, act_in, 0, sec_starts, nsec);
-    TMIX_LAUNCH_CHECK();
-    return TMIX_OK;
+    return linear_small_launch(in, W, bias, nullptr, out, M, N, K, act_in, 0, sec_starts, nsec, (hipStream_t)stream);
 }
 
 extern "C" int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,

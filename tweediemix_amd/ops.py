@@ -321,7 +321,7 @@ def timestep_embedding(values, dim, out=None):
 
 
 def linear_small_sections(x, w, bias, sec_starts, act_in=False, out=None):
-    """x [M<=16,K] fp32 against weight matrices stacked along N (w [N,K] bf16, sec_starts int32 device [nsec+1]):
+    """x [M<=256,K] fp32 against weight matrices stacked along N (w [N,K] bf16, sec_starts int32 device [nsec+1]):
     returns the flat fp32 buffer whose slice [sec_starts[s]*M, sec_starts[s+1]*M) is section s as a dense [M, width_s] matrix."""
     _need_cuda(x, w, sec_starts)
     lib = L.load()
@@ -337,7 +337,7 @@ def linear_small_sections(x, w, bias, sec_starts, act_in=False, out=None):
 
 
 def linear_small(x, w, bias=None, add=None, act_in=False, act_out=False, out=None):
-    """x [M<=16,K] fp32, w [N,K] bf16 -> [M,N] fp32."""
+    """x [M<=256,K] fp32, w [N,K] bf16 -> [M,N] fp32."""
     _need_cuda(x, w)
     lib = L.load()
     M, K = x.shape
