@@ -480,7 +480,8 @@ def main(argv=None):
             tw3, _parts3 = build_sampler(args, primary, device, seed=rank, fp8=True)
             dt3, _ = timed_fusion_steps(tw3, args, world, device, x)
             other["fp8"] = {"workload": f"{primary} deltas; attn1 q/k/v and the two FF projections of every transformer block on e4m3 operands with "
-                                        "per-row power-of-two scales (tmix_gemm_fp8), one quantiser launch per GEMM; everything else bf16",
+                                        "power-of-two scales (tmix_gemm_fp8): per row behind a quantiser launch (q/k/v, FF1), FF1 -> FF2 chained through MX blocks "
+                                        "of 32 emitted by the GEGLU epilogue; everything else bf16",
                             "dtype": "fp8", "value": S_ * args.steps / dt3, "unit": "steps/s", "ms_per_step": 1e3 * dt3 / (args.steps * S_),
                             "parity_check": parity_check(tw3, args, _parts3, primary, device)}
             del tw3
