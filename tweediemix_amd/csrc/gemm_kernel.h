@@ -416,6 +416,32 @@ gemm_conv_kernel(const Params p) {
                 }
         }
     };
+    // the same for the LDS-staged (wide) plain epilogue, in ITS lane order -- 16 bytes per lane, chunk by chunk as `chunk` below walks
+    // the tile.  Without it every chunk of a tile waits a full memory round trip for its residual rows before it can store (the
+    // residual and C may be the same tensor, so the compiler cannot hoist those loads over the previous chunk's stores): timeline
+    // of 4096 x 1280 x 1280 + residual, 128 x 160 tiles: epilogue 8.1 us of a 27.6 us workgroup.  Wave tiles up to 12 pieces.
+    constexpr int WP_I = (FN / 2) * 4 + (FN & 1) * 2;          // 16-byte residual pieces per lane per 32-row block
+    constexpr bool WPREF = FM * WP_I <= 12;
+    uint4 rw[WPREF ? FM * WP_I : 1];
+    const bool wide_res = WPREF && Rb && (p.wide & 1) && kg == 0;
+    auto prefetch_residual_wide = [&]() {
+        if constexpr (WPREF) {
+            auto grab = [&](int j0, int base, auto cf_tag) {
+                constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
+                const int rr = lane / LPR, nc = n0 + wc * TN + j0 * 32 + (lane % LPR) * 8;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const int m = m0 + wr * TM + i * 32 + ps * RPI + rr;
+                        if (m < p.M && nc < p.N) rw[i * WP_I + base + ps] = *(const uint4*)(Rb + (int64_t)m * p.ldr + nc);
+                    }
+            };
+#pragma unroll
+            for (int c = 0; c < FN / 2; ++c) grab(c * 2, c * 4, std::integral_constant<int, 2>{});
+            if constexpr (FN & 1) grab(FN - 1, (FN / 2) * 4, std::integral_constant<int, 1>{});
+        }
+    };
     // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
     if constexpr (PH) {
         constexpr int PL = PA + PB;                    // this wave's DMA instructions per slice
@@ -502,6 +528,7 @@ gemm_conv_kernel(const Params p) {
             }
             if (s + 2 < ns) wait_vmcnt<PL>(); else wait_vmcnt<0>();
             if (PREF && s == ns - 1 && Rb && plain_epi) prefetch_residual();     // rides under the last MFMA segment
+            if (s == ns - 1 && wide_res) prefetch_residual_wide();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -551,6 +578,7 @@ gemm_conv_kernel(const Params p) {
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
+            if (kt == nk - 1 && wide_res) prefetch_residual_wide();
             compute(cur);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -570,6 +598,7 @@ gemm_conv_kernel(const Params p) {
         const bool more = kt + NS - 1 < nk;
         if (more) stage(nxt, kt + NS - 1);
         if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
+        if (kt == nk - 1 && wide_res) prefetch_residual_wide();
         compute(cur);
         if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -898,7 +927,8 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                     for (int ps = 0; ps < NP; ++ps) {
                         const int m = mb + ps * RPI + rr;
-                        if (m < p.M && ncok) rv[ps] = *(const uint4*)(Rb + (int64_t)m * p.ldr + nc);
+                        if constexpr (WPREF) rv[ps] = rw[i * WP_I + (CF == 2 ? (j0 / 2) * 4 : (FN / 2) * 4) + ps];     // requested under the last K-tile
+                        else if (m < p.M && ncok) rv[ps] = *(const uint4*)(Rb + (int64_t)m * p.ldr + nc);
                     }
                 }
 #pragma unroll
