@@ -160,7 +160,11 @@ int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
  *   TMIX_F8_A_BLOCK_SCALES  scale_a is such a block-scale array [K/32][batch*M] instead of one byte per row (the instruction applies
  *                           a lane's scale to exactly its 32 K values); scale_w stays per row.  The K/32 blocks of a tile stay in
  *                           LDS for the whole K loop: K <= 7168 (256x256 tiles up to K = 2816, 256x128 beyond), M %% 4 == 0. */
-enum { TMIX_F8_A_BLOCK_SCALES = 1, TMIX_F8_GEGLU_OUT = 2 };
+/*   TMIX_F8_COPY_OUT        (tmix_gemm_bf16 and tmix_gemm_fp8, plain epilogue, no transposed region): besides the bf16 rows in C the launch
+ *                           leaves their e4m3 copy with MX block scales -- what a quantiser pass over C would produce -- for the next GEMM
+ *                           that reads C as its A operand: Ct = bytes [batch*M][ldct] (ldct >= N), and the scale array [N/32][batch*M]
+ *                           starts strideCt BYTES behind Ct.  M %% 32 == 0, N %% 32 == 0. */
+enum { TMIX_F8_A_BLOCK_SCALES = 1, TMIX_F8_GEGLU_OUT = 2, TMIX_F8_COPY_OUT = 4 };
 int tmix_gemm_fp8(const tmix_gemm_desc* d, const uint8_t* scale_a, const uint8_t* scale_w, void* stream);
 /* Row quantiser for tmix_gemm_fp8: X bf16 [rows][ld] -> Q e4m3 [rows][ldq] and scale_e8m0[r] = the smallest exponent that brings
  * max|X[r]| under 448 (K %% 8 == 0, K <= 8192).  Used on activations before each fp8 GEMM and once on the weights. */

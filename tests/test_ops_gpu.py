@@ -661,6 +661,41 @@ def test_gemm_fp8_mx_block_scales_batched_and_limits(ops):
                      torch.zeros(64, 64, device="cuda", dtype=torch.uint8), torch.zeros(64, device="cuda", dtype=torch.uint8), a_block_scales=True)
 
 
+@pytest.mark.parametrize("tile", [1, 4, 7, 12, 13, 17, 18])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_gemm_leaves_an_e4m3_copy_of_its_output_for_the_next_gemm(ops, tile, batch):
+    """TMIX_F8_COPY_OUT: next to the bf16 rows (bit-identical to a launch without the flag, statistics included) the plain epilogue
+    writes what an MX quantiser would produce from them -- e4m3 bytes and one E8M0 scale per 32 columns -- and tmix_gemm_fp8 reads
+    that pair as a block-scaled A operand (per batch row for per-row weight sets)."""
+    M, N, K = 160, 320, 128
+    a = rnd(batch, M, K, seed=20)
+    w = rnd(batch, N, K, seed=21, scale=K ** -0.5)
+    bias = rnd(N, seed=22, dtype=torch.float32)
+    res = rnd(batch, M, N, seed=23)
+    parts = ops.stats_parts(N, tile)
+    st0 = torch.zeros(parts, batch * M, 2, device="cuda")
+    st1 = torch.zeros_like(st0)
+    ref = ops.gemm(a, w, bias=bias, residual=res, tile_cfg=tile, row_stats_out=st0)
+    cp = ops.F8Copy(batch * M, N, "cuda")
+    cp.buf.fill_(0x5a)
+    out = ops.gemm(a, w, bias=bias, residual=res, tile_cfg=tile, row_stats_out=st1, f8_copy=cp)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(st0, st1)
+    q, s, deq = _mx_quantize(out.float().view(batch * M, N))
+    assert torch.equal(cp.scales, s)
+    same = (cp.q == q) | (((cp.q & 0x7f) == 0) & ((q & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+    # consumer: the copy as block-scaled A of an fp8 GEMM (weights per batch row)
+    w2 = rnd(batch, 256, N, seed=24, scale=N ** -0.5)
+    w28, sw2 = ops.quantize_fp8_rows(w2.view(batch * 256, N))
+    nxt = ops.gemm_fp8(cp.q.view(batch, M, N), cp.scales, w28.view(batch, 256, N), sw2.view(batch, 256), tile_cfg=17, a_block_scales=True)
+    want = torch.einsum("bmk,bnk->bmn", deq.view(batch, M, N), ops.dequantize_fp8_rows(w28, sw2).view(batch, 256, N))
+    close(nxt, want)
+    from tweediemix_amd.lib import TmixError
+    with pytest.raises(TmixError):                                      # rows that do not fill 32-row blocks are refused
+        ops.gemm(a[:, :150].contiguous(), w, tile_cfg=tile, f8_copy=ops.F8Copy(batch * 150, N, "cuda"))
+
+
 @pytest.mark.parametrize("tile", [16, 17])
 def test_gemm_fp8_geglu_output_as_mx_blocks_feeds_the_next_gemm(ops, tile):
     """TMIX_F8_GEGLU_OUT: the FF up-projection writes value * gelu(gate) as e4m3 with one scale per 32 output columns, exactly

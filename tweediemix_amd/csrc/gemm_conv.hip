@@ -26,6 +26,10 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
             if (cfg == 8 || cfg == 11) cfg = 9;
         }
     }
+    if (p.f8copy) {                // the e4m3 copy of C is compiled into the tilings that have registers to spare for it (F8C)
+        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18};
+        cfg = alt[cfg];
+    }
     int f8 = 0;
     if (!conv && p.scaleA) {     // fp8 operands (tmix_gemm_fp8): the phase-offset loop only; 256x128 tiles for narrow N
         f8 = p.ldScaleA ? 2 : 1;
@@ -116,7 +120,14 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
                 TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: e4m3 GEGLU output needs the GEGLU epilogue, Ct = scale buffer [N/64][ldct >= batch*M] and 8-byte aligned C rows");
             p.f8out = 1; p.scale_out = (unsigned char*)d->Ct; p.ldScaleOut = d->ldct;
         }
-    } else if (d->reserved0) TMIX_FAIL(TMIX_EINVAL, "gemm: the fp8 flags in reserved0 belong to tmix_gemm_fp8");
+    } else if (d->reserved0 & ~TMIX_F8_COPY_OUT) TMIX_FAIL(TMIX_EINVAL, "gemm: the fp8 operand flags in reserved0 belong to tmix_gemm_fp8");
+    if (d->reserved0 & TMIX_F8_COPY_OUT) {
+        if (has_trans || d->epilogue != TMIX_EPI_NONE || (d->reserved0 & TMIX_F8_GEGLU_OUT) || !d->Ct || (d->M % 32) || (d->N % 32) || (d->ldct % 8) || d->ldct < d->N
+            || (((uintptr_t)d->Ct) & 7) || d->strideCt < (int64_t)d->batch * d->M * d->ldct)
+            TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy needs the plain bf16 epilogue, M %% 32 == 0, N %% 32 == 0, Ct = bytes [batch*M][ldct >= N, %% 8 == 0] and strideCt = byte offset of the scale array behind them");
+        p.f8copy = (unsigned char*)d->Ct; p.ldF8copy = d->ldct;
+        p.scale_out = (unsigned char*)d->Ct + d->strideCt; p.ldScaleOut = (int64_t)d->batch * d->M;
+    }
     if (d->row_stats_out && (has_trans || d->epilogue != TMIX_EPI_NONE)) TMIX_FAIL(TMIX_EINVAL, "gemm: row_stats_out needs the plain bf16 epilogue");
     if (d->row_stats_out && (d->tile_cfg < 1 || d->tile_cfg > NUM_CFG || (((uintptr_t)d->row_stats_out) & 7) || (d->strideStatsOut & 1) || d->ldStatsOut < d->M))
         TMIX_FAIL(TMIX_EINVAL, "gemm: row_stats_out needs an explicit tile_cfg (its partial count depends on it) and 8-byte alignment");
@@ -136,6 +147,7 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
         if (has_trans && aligned16(d->Ct) && (d->ldct % 8) == 0 && (d->strideCt % 8) == 0) p.wide |= 4;
     }
     if (p.f8out && !(p.wide & 2)) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: e4m3 GEGLU output needs the staged epilogue");
+    if (p.f8copy && !(p.wide & 1)) TMIX_FAIL(TMIX_EALIGN, "gemm: the e4m3 copy needs the staged epilogue (16-byte aligned C / residual rows, N %% 8 == 0)");
     if (fp8 && has_trans && !(p.wide & 4)) TMIX_FAIL(TMIX_EALIGN, "gemm_fp8: the transposed region needs a 16-byte aligned Ct with ldct %% 8 == 0");
     return launch(0, p, d->batch, d->tile_cfg, (hipStream_t)stream);
 }

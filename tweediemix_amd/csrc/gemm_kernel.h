@@ -54,6 +54,7 @@ struct Params {
     const unsigned char* scaleA; const unsigned char* scaleW; int64_t strideScaleA, strideScaleW;   // fp8: E8M0 exponent per A row / W row
     int64_t ldScaleA;                 // fp8 with MX block scales on A (PH = 3): scaleA is [K/32][ldScaleA] (k-block major)
     unsigned char* scale_out; int64_t ldScaleOut; int f8out;    // GEGLU output as e4m3 bytes + [N/64][ldScaleOut] block scales
+    unsigned char* f8copy; int64_t ldF8copy;                    // plain epilogue: e4m3 COPY of the stored bf16 rows (+ scale_out [N/32][ldScaleOut])
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -96,6 +97,7 @@ gemm_conv_kernel(const Params p) {
     // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
     // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
     // scales once and the K assignment inside a 64-byte slice need only be the same for both operands.
+    constexpr bool F8C = !CONV && !LW && (BM / WM / 32) * (BN / WN / 32) <= 8;     // tilings that can also leave the e4m3 copy of C (register budget)
     constexpr bool F8 = PH >= 2;
     constexpr bool F8B = PH == 3;                      // A carries one scale per 32 K values (MX blocks), streamed with the slices
     constexpr int EB = F8 ? 1 : 2;                     // bytes per operand element
@@ -974,6 +976,22 @@ gemm_conv_kernel(const Params p) {
                         uint4 v;
                         v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
                         *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
+                        if constexpr (F8C) if (p.f8copy) {
+                            // the next GEMM's A operand: the row AS STORED, as e4m3 with one E8M0 scale per 32 columns (MX block = the 4
+                            // adjacent lanes of this row; M % 32 == 0 and N % 32 == 0, so a block's lanes are all here)
+                            const unsigned u8[4] = {v.x, v.y, v.z, v.w};
+                            float f[8], am = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(u8[k] << 16); f[2 * k + 1] = __uint_as_float(u8[k] & 0xffff0000u);
+                                                          am = fmaxf(am, fmaxf(fabsf(f[2 * k]), fabsf(f[2 * k + 1]))); }
+                            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2));
+                            const int e = e8m0_for_amax(am);
+                            const float inv = exp2_neg_int(e);
+                            int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
+                            int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, q1, true);
+                            *(uint2*)(p.f8copy + ((int64_t)bz * p.M + m) * p.ldF8copy + nc) = make_uint2((unsigned)q0, (unsigned)q1);
+                            if ((lane & 3) == 0) p.scale_out[(int64_t)(nc >> 5) * p.ldScaleOut + (int64_t)bz * p.M + m] = (unsigned char)(e + 127);
+                        }
                         if (sto) {                                 // statistics of the values AS STORED
                             const unsigned u[4] = {v.x, v.y, v.z, v.w};
                             float a1 = 0.f, a2 = 0.f;

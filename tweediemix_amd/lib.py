@@ -15,7 +15,7 @@ F32, F16, BF16 = 0, 1, 2
 STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
 CONV_S1, CONV_S2, CONV_UP2, CONV_T3, CONV_S2A = 0, 1, 2, 3, 4
-F8_A_BLOCK_SCALES, F8_GEGLU_OUT = 1, 2                    # tmix_gemm_desc.reserved0 flags of tmix_gemm_fp8
+F8_A_BLOCK_SCALES, F8_GEGLU_OUT, F8_COPY_OUT = 1, 2, 4    # tmix_gemm_desc.reserved0 flags (the first two: tmix_gemm_fp8 only)
 TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 18, 7       # 8..11: loader-wave GEMM tilings (convs map them to 7, 2, 1, 4)
 TILE_CANDIDATES = (1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15, 16, 17, 18)          # what the autotuner times by default (16, 17: phase-offset mainloop)
 TILE_EXCLUSIVE = (13, 14, 15)                                  # one workgroup per CU over the whole chip: not beside a sibling chain

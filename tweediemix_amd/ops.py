@@ -126,8 +126,32 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
     return d
 
 
-def gemm(a, w, out=None, **kw):
-    """out = epi(a @ w^T).  Allocates out ([.., M, N] or [.., M, N/2] for GEGLU) when not given."""
+class F8Copy:
+    """Receiver of TMIX_F8_COPY_OUT: one byte buffer holding the e4m3 copy [rows, N] of a GEMM's bf16 output and, behind it,
+    the MX block scales [N/32, rows] -- the pair tmix_gemm_fp8 takes as a block-scaled A operand."""
+
+    @staticmethod
+    def bytes_for(rows, N):
+        return (rows * N + 255) // 256 * 256 + (N // 32) * rows
+
+    def __init__(self, rows, N, device, buf=None):
+        self.rows, self.N = rows, N
+        self.off = (rows * N + 255) // 256 * 256
+        self.nbytes = self.off + (N // 32) * rows
+        self.buf = buf if buf is not None else torch.empty(self.nbytes, device=device, dtype=torch.uint8)
+        assert self.buf.numel() >= self.nbytes and self.buf.dtype == torch.uint8
+        self.q = self.buf[:rows * N].view(rows, N)
+        self.scales = self.buf[self.off:self.off + (N // 32) * rows].view(N // 32, rows)
+
+    def attach(self, d):
+        assert d.batch * d.M == self.rows and d.N == self.N
+        d.Ct, d.ldct, d.strideCt = self.buf.data_ptr(), self.N, self.off
+        d.reserved0 |= L.F8_COPY_OUT
+
+
+def gemm(a, w, out=None, f8_copy=None, **kw):
+    """out = epi(a @ w^T).  Allocates out ([.., M, N] or [.., M, N/2] for GEGLU) when not given.
+    f8_copy: an F8Copy that also receives the e4m3 + MX-block-scale copy of the stored rows."""
     _need_cuda(a, w)
     lib = L.load()
     if out is None and kw.get("out_f32") is None and not (kw.get("out_t") is not None and kw.get("n_trans_begin", -1) == 0):
@@ -137,6 +161,8 @@ def gemm(a, w, out=None, **kw):
             No = kw["n_trans_begin"]
         out = torch.empty(*a.shape[:-1], No, device=a.device, dtype=BF16)
     d = make_gemm_desc(a, w, out, **kw)
+    if f8_copy is not None:
+        f8_copy.attach(d)
     L.check(lib.tmix_gemm_bf16(C.byref(d), _stream()), "tmix_gemm_bf16")
     return out if out is not None else kw.get("out_f32")
 
@@ -163,7 +189,7 @@ def dequantize_fp8_rows(q, scale):
     return q.view(torch.float8_e4m3fn).float() * torch.exp2(scale.float() - 127.0).unsqueeze(-1)
 
 
-def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, **kw):
+def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, f8_copy=None, **kw):
     """gemm() on e4m3 operands with per-row E8M0 scales (tmix_gemm_fp8): a8 [.., M, K] uint8 + sa [.., M]; w8 [.., N, K] + sw [.., N].
     a_block_scales: sa is the MX block form [K/32, rows] (k-block major) instead.
     f8_out=(c8 uint8 [.., M, N/2], scales uint8 [N/64, rows]) with geglu=True: the GEGLU result leaves as e4m3 + block scales."""
@@ -188,6 +214,8 @@ def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, **kw):
     if a_block_scales:
         assert sa.dim() == 2 and sa.shape[0] == a8.shape[-1] // 32
         d.reserved0 = L.F8_A_BLOCK_SCALES
+    if f8_copy is not None:
+        f8_copy.attach(d)
     L.check(lib.tmix_gemm_fp8(C.byref(d), sa.data_ptr(), sw.data_ptr(), _stream()), "tmix_gemm_fp8")
     return out if out is not None else kw.get("out_f32")
 

@@ -464,12 +464,19 @@ class UNetPlan:
         self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", self.B, HW, Cc))
         return out
 
-    def _gemm(self, a, w, out, fp8_key=None, **kw):
+    def _gemm(self, a, w, out, fp8_key=None, f8_copy=None, a8=None, **kw):
+        """f8_copy: an ops.F8Copy that also receives the e4m3 + MX-block copy of the stored rows (fp8 plans: the next projection's A
+        operand); a8: such a copy of `a`, used instead of a quantiser launch when this GEMM runs on fp8 operands."""
         if fp8_key is not None and self.fp8:
-            return self._gemm_fp8(a, fp8_key, out, **kw)
+            if a8 is not None:
+                a = (a8.q.view(*a.shape), a8.scales)
+            return self._gemm_fp8(a, fp8_key, out, f8_copy=f8_copy, **kw)
         if kw.get("row_stats_out") is not None:
             kw.setdefault("tile_cfg", 1)            # the partial count depends on the tiling: never TMIX_TILE_AUTO
         d = ops.make_gemm_desc(a, w, out, **kw)
+        if f8_copy is not None:
+            f8_copy.attach(d)
+            self.keep.append(f8_copy)
         if kw.get("row_stats_out") is not None:
             self._ln_links.append((d, []))
         elif kw.get("ln_stats") is not None:
@@ -484,7 +491,7 @@ class UNetPlan:
         self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
         return out
 
-    def _gemm_fp8(self, a, key, out, f8_out=None, **kw):
+    def _gemm_fp8(self, a, key, out, f8_out=None, f8_copy=None, **kw):
         """tmix_gemm_fp8 against the cached e4m3 copy of weight `key` (key = (name, row_sets) for per-row LoRA weight sets).
         a: bf16 rows -- quantised by one tmix_quantize_fp8_rows launch in front of the GEMM -- or a pair (e4m3 bytes, MX block
         scales [K/32][rows]) as left by a GEMM planned with f8_out=(bytes [M][N/2], scales [N/64][M]) (GEGLU epilogue only):
@@ -514,6 +521,9 @@ class UNetPlan:
             d.Ct, d.ldct = cs.data_ptr(), cs.shape[1]
             flags |= L.F8_GEGLU_OUT
         d.reserved0 = flags
+        if f8_copy is not None:
+            f8_copy.attach(d)
+            self.keep.append(f8_copy)
         if kw.get("row_stats_out") is not None:
             self._ln_links.append((d, []))
         elif kw.get("ln_stats") is not None:
@@ -595,7 +605,7 @@ class UNetPlan:
             A.put(sc)
         return out
 
-    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, fp8=False, **kw):
+    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, fp8=False, a8=None, **kw):
         """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM.
         ln: statistics of a LayerNorm folded into this projection (weights stored folded, see UNetWeights.fold);
         stats_out: accumulate the statistics of the rows this projection writes."""
@@ -613,6 +623,7 @@ class UNetPlan:
         w = self._rows(key) if self.routed else W[key]
         if fp8 and self.fp8:
             kw["fp8_key"] = (key + "_rows", tuple(self.row_sets)) if self.routed else key
+            kw["a8"] = a8
         return self._gemm(a.view(*shp, Cin), w, out.view(*shp, out.shape[-1]), **kw)
 
     def _rows(self, key, suffix=""):
@@ -631,8 +642,14 @@ class UNetPlan:
         g = self._gn(x, Cc, S, name + ".norm", 1e-6, False)
         h = A.get(B, S, Cc)
         st = self._ln_stats(S, Cc)
+        # fp8 plans: every GEMM that writes the residual stream h also leaves its e4m3 + MX-block copy (TMIX_F8_COPY_OUT), which the
+        # next projection (attn1 q/k/v, attn2 to_q, FF1) reads as its A operand -- no quantiser launches inside a block
+        h8 = None
+        if self.fp8 and self.fp8_chain_ff and n and S % 32 == 0 and Cc % 32 == 0:
+            h8buf = A.get(ops.F8Copy.bytes_for(B * S, Cc), dtype=torch.uint8)
+            h8 = ops.F8Copy(B * S, Cc, self.dev, buf=h8buf)
         self._gemm(g.view(B * S, Cc), W[name + ".proj_in.weight"], h.view(B * S, Cc), bias=W[name + ".proj_in.bias"],
-                   row_stats_out=st if n else None)
+                   row_stats_out=st if n else None, f8_copy=h8)
         A.put(g)
         vt = self._vt_buf(Cc, S)
         for i in range(n):
@@ -640,29 +657,30 @@ class UNetPlan:
             a1, a2 = tb + ".attn1", tb + ".attn2"
             # --- self attention; norm1 is folded into the q/k/v projection
             qk = A.get(B, S, 2 * Cc)
-            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc, fp8=True)
+            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc, fp8=True, a8=h8)
             ao = A.get(B, S, Cc)
             self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
             A.put(qk)
-            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st)
+            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8)
             A.put(ao)
             # --- cross attention against the cached K / V^T; norm2 folded into to_q
             q = A.get(B, S, Cc)
-            self._proj(h, a2 + ".q", q, S, Cc, ln=st)
+            self._proj(h, a2 + ".q", q, S, Cc, ln=st, fp8=h8 is not None, a8=h8)
             ao = A.get(B, S, Cc)
             self._attn(q, self.kv.k[a2], self.kv.vt[a2], ao, H, S, self.kv.Lk)
             A.put(q)
-            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st)
+            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8)
             A.put(ao)
             # --- feed forward: norm3 folded into the first GEMM, GEGLU fused in its epilogue
             if self.fp8 and self.fp8_chain_ff:
                 # the intermediate leaves FF1 as e4m3 with one E8M0 scale per 32 columns and FF2 reads it as block-scaled A
                 f = A.get(B * S, 4 * Cc, dtype=torch.uint8)
                 fs = A.get(4 * Cc // 32, B * S, dtype=torch.uint8)
-                self._gemm_fp8(h.view(B * S, Cc), tb + ".ff1", None, f8_out=(f, fs), bias=W[tb + ".ff1.bias"], geglu=True,
-                               ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"])
+                self._gemm_fp8((h8.q, h8.scales) if h8 is not None else h.view(B * S, Cc), tb + ".ff1", None, f8_out=(f, fs),
+                               bias=W[tb + ".ff1.bias"], geglu=True, ln_stats=st, ln_colsum=W[tb + ".ff1.colsum"])
                 self._gemm_fp8((f, fs), tb + ".ff.net.2.weight", h.view(B * S, Cc), bias=W[tb + ".ff.net.2.bias"],
-                               residual=h.view(B * S, Cc), row_stats_out=st if i + 1 < n else None)
+                               residual=h.view(B * S, Cc), row_stats_out=st if i + 1 < n else None,
+                               f8_copy=h8 if i + 1 < n else None)
                 A.put(f, fs)
                 continue
             f = A.get(B * S, 4 * Cc)
@@ -675,6 +693,8 @@ class UNetPlan:
         self._gemm(h.view(B * S, Cc), W[name + ".proj_out.weight"], out.view(B * S, Cc), bias=W[name + ".proj_out.bias"],
                    residual=x.view(B * S, Cc))
         A.put(h)
+        if h8 is not None:
+            A.put(h8buf)
         return out
 
     def _cat(self, x1, C1, x2, C2, HW):
