@@ -222,6 +222,15 @@ def insitu_profile(tw, reps=3):
             shapes[k][0] += 1; shapes[k][1] += d; shapes[k][2] += fl
     for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
         print(f"  {str(k):64s} n={cnt:4d} total={ms:7.3f}ms avg={1e3 * ms / cnt:7.1f}us {fl / ms / 1e9 if ms else 0:6.0f}TF", file=sys.stderr)
+    if os.environ.get("TMIX_BENCH_SHAPES"):            # kernel boundaries: start of launch i+1 minus end of launch i, by class pair
+        gaps = collections.defaultdict(list)
+        for i in range(len(meta) - 1):
+            gaps[(meta[i][0], meta[i + 1][0])].append((int(sl[i + 1][0]) - int(sl[i][1])) * tick * 1e3)
+        tot = sum(sum(v) for v in gaps.values())
+        print(f"  boundaries between instrumented launches: {sum(len(v) for v in gaps.values())}, {tot / 1e3:.3f} ms in total", file=sys.stderr)
+        for k, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
+            v = sorted(v)
+            print(f"    {k[0]:5s} -> {k[1]:5s} n={len(v):4d} sum={sum(v) / 1e3:6.3f}ms median={v[len(v) // 2]:6.2f}us p90={v[int(len(v) * 0.9)]:6.2f}us max={v[-1]:7.2f}us", file=sys.stderr)
 
     def union(iv):
         tot, end = 0, -1
