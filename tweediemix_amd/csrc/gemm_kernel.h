@@ -813,10 +813,13 @@ gemm_conv_kernel(const Params p) {
                     for (int g = 0; g < 2; ++g) {
                         const int nv = nb + g * 8 + lhi * 4;
                         float o[4];
+                        float4 ba = {0.f, 0.f, 0.f, 0.f}, bg = ba;      // one 16-byte load each (the bias is 16-byte aligned, nv % 4 == 0)
+                        if (bias && nb < p.N) { ba = *(const float4*)(bias + nv); bg = *(const float4*)(bias + nv + 16); }
+                        const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
-                            if (bias && nb < p.N) { a = fmaf(a, rs_row[i], bias[nv + r]); gt = fmaf(gt, rs_row[i], bias[nv + 16 + r]); }
+                            if (bias && nb < p.N) { a = fmaf(a, rs_row[i], bav[r]); gt = fmaf(gt, rs_row[i], bgv[r]); }
                             else { a *= rs_row[i]; gt *= rs_row[i]; }
                             o[r] = a * gelu_erf_f(gt);
                         }
