@@ -28,6 +28,8 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     }
     if (p.f8copy) {                // the e4m3 copy of C is compiled into the tilings that have registers to spare for it (F8C)
         static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18};
+        // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
+        if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
         cfg = alt[cfg];
     }
     int f8 = 0;

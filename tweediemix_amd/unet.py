@@ -561,6 +561,8 @@ class UNetPlan:
 
     def _link_ln(self):
         for prod, cons in self._ln_links:
+            if (prod.reserved0 & L.F8_COPY_OUT) and prod.tile_cfg == 14:
+                prod.tile_cfg = 12          # the e4m3 copy is not compiled into 256x320; its stand-in writes another partial count
             parts = ops.stats_parts(prod.N, prod.tile_cfg)
             for c in cons:
                 c.ln_parts = parts
