@@ -217,3 +217,35 @@ def test_weights_tolerate_checkpoints_without_attn1_lora_or_custom_kv():
     Wc = U.UNetWeights(cfg, sd, "cpu", ("custom", cc))
     kv = Wc[a2 + ".kv_rows"]
     assert kv.shape[0] == 3 and torch.equal(kv[2], kv[0]) and not torch.equal(kv[1], kv[0])
+
+
+def test_stacked_time_projection_sections_cover_every_resnet():
+    """UNetWeights.stacked_time_proj (one tmix_linear_small_sections launch for all ResnetBlock2D.time_emb_proj layers): the stack
+    is the per-resnet matrices in a fixed order, the section table is their running row count, and every resnet has a section."""
+    from tweediemix_amd import unet as U, weights as Wt
+    cfg = U.TINY
+    sd = Wt.synthetic_state_dict(cfg, seed=5, device="cpu", dtype=torch.float32)
+    W = U.UNetWeights(cfg, sd, "cpu")
+    w, b, starts, names = W.stacked_time_proj()
+    assert names == sorted(k[:-len(".time_emb_proj.weight")] for k in sd if k.endswith(".time_emb_proj.weight"))
+    st = starts.tolist()
+    assert st[0] == 0 and st[-1] == w.shape[0] == b.shape[0] and len(st) == len(names) + 1
+    for i, n in enumerate(names):
+        assert torch.equal(w[st[i]:st[i + 1]], W[n + ".time_emb_proj.weight"])
+        assert torch.equal(b[st[i]:st[i + 1]], W[n + ".time_emb_proj.bias"].float())
+    assert W.stacked_time_proj() is W.stacked_time_proj()          # built once per checkpoint
+
+
+def test_f8copy_layout():
+    """ops.F8Copy: e4m3 bytes [rows, N] first, the MX block scales [N/32, rows] at a 256-byte aligned offset behind them -- the
+    (Ct, ldct, strideCt) triple TMIX_F8_COPY_OUT reads from the descriptor."""
+    from tweediemix_amd import ops, lib as L
+    rows, N = 96, 160
+    cp = ops.F8Copy(rows, N, "cpu")
+    assert cp.off % 256 == 0 and cp.off >= rows * N and cp.nbytes == ops.F8Copy.bytes_for(rows, N) == cp.off + (N // 32) * rows
+    assert cp.q.shape == (rows, N) and cp.scales.shape == (N // 32, rows)
+    assert cp.q.data_ptr() == cp.buf.data_ptr() and cp.scales.data_ptr() == cp.buf.data_ptr() + cp.off
+    d = L.GemmDesc()
+    d.batch, d.M, d.N = 2, rows // 2, N
+    cp.attach(d)
+    assert d.Ct == cp.buf.data_ptr() and d.ldct == N and d.strideCt == cp.off and d.reserved0 == L.F8_COPY_OUT
