@@ -1,6 +1,6 @@
 """cold-operand single launches (the in-sequence regime): tmix_gemm_bf16 next to torch.matmul (hipBLASLt) after a cache flush,
 with A warm (just written by the previous kernel in the real sequence) and W cold."""
-import os, sys, ctypes as C, torch
+import os, sys, json, ctypes as C, torch
 sys.path.insert(0, os.getcwd())
 from tweediemix_amd import ops, lib as L
 lib = L.load(); BF = torch.bfloat16
@@ -16,14 +16,17 @@ def once(fn, warm):
         e0.record(); fn(); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     return sorted(ts)[1]
+rows = []
 for (M, N, K) in ((4096, 1280, 1280), (4096, 3840, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (16384, 640, 640), (16384, 5120, 640)):
     a = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
     out = torch.empty(M, N, device="cuda", dtype=BF)
     wt = w.t()
     best = None
-    for cfg in (1, 2, 7, 9):
+    for cfg in (1, 2, 4, 7, 12, 14, 16, 17, 18):
         d = ops.make_gemm_desc(a, w, out, tile_cfg=cfg)
         t = once(lambda: lib.tmix_gemm_bf16(C.byref(d), st), [a])
         best = min(best, (t, cfg)) if best else (t, cfg)
     tb = once(lambda: torch.matmul(a, wt, out=out), [a])
+    rows.append({'M': M, 'N': N, 'K': K, 'tmix_cfg': best[1], 'tmix_us': best[0], 'torch_matmul_us': tb})
     print(f"{M}x{N}x{K}: A warm / W cold: tmix cfg{best[1]} {best[0]:6.1f} us | torch.matmul {tb:6.1f} us", flush=True)
+if len(sys.argv) > 1: json.dump({'what': 'single launch after a cache flush, A re-warmed, W cold (the in-sequence regime)', 'rows': rows}, open(sys.argv[1], 'w'), indent=1)

@@ -46,7 +46,8 @@ __device__ __forceinline__ int e8m0_for_amax(float amax) {
     int e = (int)((bits >> 23) & 0xff) - 127 + ((bits & 0x7fffff) ? 1 : 0);
     return e < -127 ? -127 : (e > 127 ? 127 : e);
 }
-__device__ __forceinline__ float exp2_neg_int(int e) { return __uint_as_float((unsigned)(127 - e) << 23); }      // 2^-e, e in [-127, 127]
+// 2^-e, e in [-127, 127] (e = 127 -- only reachable from non-finite input -- is the denormal 2^-127, not 0: 0 * inf would be NaN bytes)
+__device__ __forceinline__ float exp2_neg_int(int e) { return e >= 127 ? __uint_as_float(0x00400000u) : __uint_as_float((unsigned)(127 - e) << 23); }
 
 // thread-local error string (host side)
 void tmix_set_error(const char* fmt, ...);

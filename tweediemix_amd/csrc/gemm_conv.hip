@@ -17,17 +17,18 @@ int pick_cfg(const Params& p, int batch) {
 
 int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
+    if (cfg == 8) cfg = 19; else if (cfg == 9) cfg = 2; else if (cfg == 10) cfg = 1; else if (cfg == 11) cfg = 4;   // round-1 loader-wave tilings, retired (3 waves / SIMD register budget: they spilled)
+    if (cfg == 6) cfg = 4;      // 256x256 over four waves (128x128 wave tiles) is retired: it spilled and lost everywhere; same tile shape over eight waves
     if (p.n_trans_begin >= 0) {
         int bm = 0, bn = 0;
         tmix_gemm_tile_shape(cfg, &bm, &bn);
         if (p.n_trans_begin % bn) cfg = 2;                                     // the boundary must fall on a tile edge (N = 3 x 320: 640)
         if (!(p.wide & 4)) {                                                   // narrow (unstaged) transposed stores need square wave tiles
             if (cfg == 4 || cfg == 5 || cfg == 7 || cfg >= 12) cfg = 2;      // (18 included)
-            if (cfg == 8 || cfg == 11) cfg = 9;
         }
     }
     if (p.f8copy) {                // the e4m3 copy of C is compiled into the tilings that have registers to spare for it (F8C)
-        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18};
+        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12};
         // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
         if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
         cfg = alt[cfg];
@@ -35,17 +36,19 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     int f8 = 0;
     if (!conv && p.scaleA) {     // fp8 operands (tmix_gemm_fp8): the phase-offset loop only; 256x128 tiles for narrow N
         f8 = p.ldScaleA ? 2 : 1;
+        const int asked = cfg;
         cfg = (cfg == 17 || (cfg != 16 && (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch < 160)) ? 17 : 16;
         if (f8 == 2 && cfg == 16 && p.K / 32 > f8_block_cap(256)) cfg = 17;    // the tile's block scales stay in LDS beside the ring
+        // the consumers of row_stats_out were told the partial count of the REQUESTED tiling (tmix_gemm_stats_parts): never change the width under them
+        if (p.stats_out && asked != cfg) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg %d cannot run this launch (K / 32 = %d block scales per row exceed the 256x256 tile's LDS budget); "
+                                                                "with row_stats_out request tile_cfg 17 explicitly", asked, p.K / 32);
     }
     if (conv) {
         // the phase-offset and loader-wave mainloops exist for the plain GEMM only (the im2col gather's per-row offset tables do
         // not fit a loader wave's register budget, and the conv mainloop already runs at 0.8-1.0 PFLOP/s): nearest plain tiling
-        if (cfg == 16 || cfg == 11) cfg = 4;
-        else if (cfg == 17 || cfg == 9) cfg = 2;
-        else if (cfg == 8) cfg = 7;
-        else if (cfg == 10) cfg = 1;
-        else if (cfg == 18) cfg = 12;
+        if (cfg == 16) cfg = 4;
+        else if (cfg == 17) cfg = 2;
+        else if (cfg >= 18) cfg = 12;
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
     int rc = launch_group0(cfg, conv, f8, p, batch, st);
     if (rc == -999) rc = launch_group1(cfg, conv, f8, p, batch, st);
@@ -61,7 +64,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
                                               {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160},
-                                              {256, 256}, {256, 128}, {128, 160}};
+                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

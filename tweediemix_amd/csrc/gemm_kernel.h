@@ -26,6 +26,14 @@
 // gemm_conv.hip holds the host entry points and the tiling switch.
 namespace tmix_gemm {
 
+// TMIX_ABL (dev builds under tools/ab/ only; the shipped library is built without it): ablations that locate the bound of a
+// launch -- bit 0: every workgroup stages tile (0, 0) (operands L2-hot, no fabric traffic), bit 1: no MFMAs (fragments are read
+// and kept alive), bit 2: no LDS-DMA inside the K loop (the prologue's tiles are re-read), bit 3: no epilogue stores.
+#ifndef TMIX_ABL
+#define TMIX_ABL 0
+#endif
+constexpr int ABL = TMIX_ABL;
+
 constexpr int BK = 64;
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
@@ -89,7 +97,7 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 // (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
-__global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? 3 : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
+__global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? (NS * (BM + BN) * 128 > 80 * 1024 ? 2 : 3) : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
 gemm_conv_kernel(const Params p) {
     static_assert(!PH || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
     static_assert(KS == 1 || (KS == 2 && !LW && !PH && !CONV), "in-workgroup split-K geometry");
@@ -107,7 +115,7 @@ gemm_conv_kernel(const Params p) {
     constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
     constexpr int SLOT = (BM + BN) * 64;               // PH: one 32-wide K slice of both operands (rows of 64 bytes)
     constexpr int RING = PH ? 4 * SLOT : NS * STAGE;   // bytes of the staging ring (the fused-LayerNorm block sits behind it)
-    constexpr int SW = LW ? 1 : NW * KS;               // waves that share the staging of a K-tile
+    constexpr int SW = LW ? LW : NW * KS;              // waves that share the staging of a K-tile (LW: the loader waves)
     constexpr int IA = BM / 8, IB = BN / 8;            // LDS-DMA instructions per stage (8 rows of 128 bytes each)
     // ... per staging wave; when the waves do not divide them (64x160 over 5 waves) a surplus slot re-stages the last rows
     // (same bytes to the same place), so every wave issues the same count and the counted vmcnt waits stay valid
@@ -126,9 +134,9 @@ gemm_conv_kernel(const Params p) {
     const bool prof_on = p.prof != nullptr && tid == 0;
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
     if (prof_on) pt0 = prof_enter(p.prof, (blockIdx.x | blockIdx.y) == 0, p.prof_detail);
-    const bool loader = LW && (w == NW);               // wave-uniform role
+    const bool loader = LW && (w >= NW);               // wave-uniform role
     const bool stager = LW ? loader : true;
-    const int sw_id = LW ? 0 : w;                      // this wave's slot among the staging waves
+    const int sw_id = LW ? max(w - NW, 0) : w;         // this wave's slot among the staging waves
 
     // Tile order: each XCD (private 4 MiB L2) owns a contiguous range of logical ids, and ids sweep GM tile-rows
     // per tile-column, so the ~64 tiles resident on an XCD at any time form a compact GM x (64/GM) patch that
@@ -141,6 +149,7 @@ gemm_conv_kernel(const Params p) {
     const int rem = bid - grp * per_group;
     const int tile_n = rem / gsize, tile_m = first_m + (rem - tile_n * gsize);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0l = (ABL & 1) ? 0 : m0, n0l = (ABL & 1) ? 0 : n0;      // rows the STAGING reads (ablation bit 0: tile (0, 0))
     const int bz = blockIdx.y;
 
     const bf16_t* Ab = (const bf16_t*)((const char*)p.A + (int64_t)bz * p.strideA * EB);      // strides count elements (fp8: bytes)
@@ -162,19 +171,20 @@ gemm_conv_kernel(const Params p) {
     if constexpr (LW) {
         if (loader) {
 #pragma unroll
-            for (int par = 0; par < 2; ++par) {
+            for (int pp = 0; pp < 2; ++pp) {
+                const int par = (LW == 2) ? sw_id : pp;   // two loaders: instruction parity = loader id (both slots hold it)
                 const unsigned sw = ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 8;
-                swp[par] = sw;
-                woffp[par] = ((unsigned)(n0 + par * 8 + lrow) * (unsigned)p.ldw + sw) * 2u;
-                wmaxp[par] = ((unsigned)(p.N - 1) * (unsigned)p.ldw + sw) * 2u;
-                aoffp[par] = ((unsigned)(m0 + par * 8 + lrow) * (unsigned)p.lda + sw) * 2u;
-                amaxp[par] = ((unsigned)(p.M - 1) * (unsigned)p.lda + sw) * 2u;
+                swp[pp] = sw;
+                woffp[pp] = ((unsigned)(n0l + par * 8 + lrow) * (unsigned)p.ldw + sw) * 2u;
+                wmaxp[pp] = ((unsigned)(p.N - 1) * (unsigned)p.ldw + sw) * 2u;
+                aoffp[pp] = ((unsigned)(m0l + par * 8 + lrow) * (unsigned)p.lda + sw) * 2u;
+                amaxp[pp] = ((unsigned)(p.M - 1) * (unsigned)p.lda + sw) * 2u;
             }
             if constexpr (CONV) {
                 const int hw = p.Ho * p.Wo;
 #pragma unroll
                 for (int r = 0; r < RA; ++r) {
-                    int m = m0 + r * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+                    int m = m0l + r * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
                     pb[r] = m / hw; const int rem = m - pb[r] * hw;
                     py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
                 }
@@ -186,14 +196,14 @@ gemm_conv_kernel(const Params p) {
     for (int r = 0; r < RB; ++r) {
         const int idx = slot_w(r);
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
-        int n = n0 + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
+        int n = n0l + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
         woff[r] = ((unsigned)n * (unsigned)p.ldw + sw) * 2u;
     }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         const int idx = slot_a(r);
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;
-        int m = m0 + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+        int m = m0l + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
         asw[r] = sw;
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo;
@@ -215,12 +225,12 @@ gemm_conv_kernel(const Params p) {
         const unsigned ch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * (16 / EB));  // swizzled source chunk (elements)
 #pragma unroll
         for (int r = 0; r < PA; ++r) {
-            int m = m0 + (r * NW + w) * 16 + (lane >> 2); if (m > p.M - 1) m = p.M - 1;
+            int m = m0l + (r * NW + w) * 16 + (lane >> 2); if (m > p.M - 1) m = p.M - 1;
             phA[r] = ((unsigned)m * (unsigned)p.lda + ch) * (unsigned)EB;
         }
 #pragma unroll
         for (int r = 0; r < PB; ++r) {
-            int n = n0 + (r * NW + w) * 16 + (lane >> 2); if (n > p.N - 1) n = p.N - 1;
+            int n = n0l + (r * NW + w) * 16 + (lane >> 2); if (n > p.N - 1) n = p.N - 1;
             phW[r] = ((unsigned)n * (unsigned)p.ldw + ch) * (unsigned)EB;
         }
     }
@@ -263,14 +273,14 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + slot_a(r) * 1024);
-            else if constexpr (LW) blds16(rsA, min(aoffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.lda), amaxp[r & 1]),
-                                          (unsigned)kt * (BK * 2), sA + r * 1024);
+            else if constexpr (LW) blds16(rsA, min(aoffp[(r * LW) & 1] + (unsigned)(slot_a(r) >> 1) * (unsigned)(32 * p.lda), amaxp[(r * LW) & 1]),
+                                          (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
             else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            if constexpr (LW) blds16(rsW, min(woffp[r & 1] + (unsigned)(r >> 1) * (unsigned)(32 * p.ldw), wmaxp[r & 1]),
-                                     (unsigned)kt * (BK * 2), sW + r * 1024);
+            if constexpr (LW) blds16(rsW, min(woffp[(r * LW) & 1] + (unsigned)(slot_w(r) >> 1) * (unsigned)(32 * p.ldw), wmaxp[(r * LW) & 1]),
+                                     (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
             else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
         }
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < p.ntaps) conv_tap_offsets(); } }
@@ -371,34 +381,6 @@ gemm_conv_kernel(const Params p) {
     // acc[i][j] then belongs to W-fragment i x A-fragment j and a lane holds 4 consecutive m for one n.
     const int offA = (wr * TM + l31) * 128, offW = A_TILE + (wc * TN + l31) * 128;
     const int off_a = tswap ? offW : offA, off_b = tswap ? offA : offW;
-    auto compute = [&](int buf) {
-        const char* pa = smem + buf * STAGE + off_a;
-        const char* pb = smem + buf * STAGE + off_b;
-        // fragments of k-step kk+1 are requested before the MFMAs of k-step kk issue (register double buffer)
-        frag_ab a[2][FM], b[2][FN];
-        constexpr int KPW = 4 / KS;                    // k-steps of this wave's split-K group
-        const int k0 = kg * KPW;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) a[0][i] = *(const frag_ab*)(pa + i * 32 * 128 + (((k0 * 2 + lhi) ^ fsw) << 4));
-#pragma unroll
-        for (int j = 0; j < FN; ++j) b[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + (((k0 * 2 + lhi) ^ fsw) << 4));
-#pragma unroll
-        for (int kk = 0; kk < KPW; ++kk) {
-            if (kk < KPW - 1) {
-                const int sw = (((k0 + kk + 1) * 2 + lhi) ^ fsw) << 4;
-#pragma unroll
-                for (int i = 0; i < FM; ++i) a[(kk + 1) & 1][i] = *(const frag_ab*)(pa + i * 32 * 128 + sw);
-#pragma unroll
-                for (int j = 0; j < FN; ++j) b[(kk + 1) & 1][j] = *(const frag_ab*)(pb + j * 32 * 128 + sw);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk & 1][j], a[kk & 1][i], acc[i][j], 0, 0, 0);
-        }
-    };
-
     // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
     const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
     const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU && !(p.wide & 1);
@@ -549,6 +531,7 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
                         if constexpr (F8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, f8sW[j], 0, F8B ? f8use[i] : f8sA[i]);
+                        else if constexpr (ABL & 2) asm volatile("" :: "v"(b[kk][j]), "v"(a[kk][i]));
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
                         const int idx = (kk * FM + i) * FN + j;
                         if constexpr (ST) {
@@ -568,46 +551,117 @@ gemm_conv_kernel(const Params p) {
             asm volatile("" ::: "memory");
         };
         int s = 0;
-        for (; s + 3 < ns; ++s) slice(s, std::true_type{});
+        if constexpr (!(ABL & 4)) for (; s + 3 < ns; ++s) slice(s, std::true_type{});
         for (; s < ns; ++s) slice(s, std::false_type{});
         if (!grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     } else
-    if constexpr (LW) {
-        ln_reduce();                                   // ---- math waves: LDS reads + MFMA only
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (prof_on) pt1 = prof_now();
-        int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
-            if (kt == nk - 1 && wide_res) prefetch_residual_wide();
-            compute(cur);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            cur = (cur + 1 == NS) ? 0 : cur + 1;
-        }
-    } else {
+    {
+    // ---- 4-wave / split-K / loader-wave tilings: software-pipelined K loop.
+    // These tilings run ONE math wave per SIMD (two with KS = 2), so nothing hides a wave's own LDS latency.  Left to itself the
+    // compiler placed every ds_read_b128 one or two instructions in front of the MFMA that consumes it (`s_waitcnt lgkmcnt(1)`
+    // before nearly every MFMA, four fragment registers recycled) and the round-2 loop ran fragment reads, MFMAs and LDS-DMA issue
+    // strictly one after the other -- ablations on 4096 x 1280 x 1280, 128 x 160 tiles (tools/jobs/r3b_ablate.sh): 18.8 us of K
+    // loop, 14.3 without the DMA, 15.0 without the MFMAs, 8.2 with neither, against 5.3 us of MFMA time.  Here the fragments of
+    // k-step kk + 1 are requested between the MFMAs of k-step kk (issue order pinned by sched_barrier), the K-tile hand-over
+    // (all fragments in registers, counted vmcnt, barrier) sits in FRONT of the last k-step's MFMAs with the next tile's first
+    // fragments requested right behind it, and a staging wave spreads the LDS-DMA instructions of tile kt + NS - 1 over the
+    // MFMAs of k-step 0.  With loader waves (LW) the math waves run the same loop without any VMEM instruction.
+    if constexpr (!LW) {
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) stage(s, s);
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) stage(s, s);
+    }
     ln_reduce();
-    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+    if constexpr (!LW) { if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (prof_on) pt1 = prof_now();
     int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + NS - 1 < nk;
-        if (more) stage(nxt, kt + NS - 1);
-        if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
-        if (kt == nk - 1 && wide_res) prefetch_residual_wide();
-        compute(cur);
-        if (more) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+    constexpr int KPW = 4 / KS;                        // k-steps of this wave's split-K group
+    const int k0 = kg * KPW;
+    frag_ab fa[2][FM], fb[2][FN];
+    constexpr int NMF = FM * FN, NRD = FM + FN;
+    // One k-step with its issue order PINNED (a sched_barrier after every micro-group): MFMA q on register set S, then that
+    // MFMA's share of the NEXT k-step's fragment reads (ring slot rbuf, k-step rkk, into set 1 - S: A fragments first, they feed
+    // every MFMA of the row) and, when nd > 0, of the nd LDS-DMA instructions of K-tile dkt into ring slot dbuf.  S and nd are
+    // constants at every call site (the loops are fully unrolled), so all register-array indices fold.
+    // ROLL (tilings at the register limit: 256 x 320 over eight waves): MFMAs run column by column (j-major), the W fragments are
+    // SINGLE-buffered -- fragment j is re-read for the next k-step right behind its last MFMA of this one, FM * (FN - 1 - j) + FM
+    // MFMAs ahead of its next use -- and only the FM A fragments are double-buffered: 2 * FM + FN fragment registers instead of
+    // 2 * (FM + FN), which is what keeps that tiling free of scratch spills (spill traffic would also break the counted vmcnt).
+    constexpr bool ROLL = NW * KS > 4 && NMF * 16 + 2 * NRD * 4 > 200;
+    auto kstep = [&](const int S, const int rbuf, const int rkk, const int nd, const int dbuf, const int dkt) {
+        const char* pa = smem + rbuf * STAGE + off_a;
+        const char* pb = smem + rbuf * STAGE + off_b;
+        const int sw = (((k0 + rkk) * 2 + lhi) ^ fsw) << 4;
+        char* sA = smem + dbuf * STAGE;
+        constexpr int RPQ = (NRD + NMF - 1) / NMF;
+        const int dpq = (nd + NMF - 1) / NMF;
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            const int i = ROLL ? q % FM : q / FN, j = ROLL ? q / FM : q - (q / FN) * FN;
+            const int SB = ROLL ? 0 : S;
+            if constexpr (ABL & 2) asm volatile("" :: "v"(fb[SB][j]), "v"(fa[S][i]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SB][j], fa[S][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ROLL) {
+                if (q < FM) fa[1 - S][q] = *(const frag_ab*)(pa + q * 32 * 128 + sw);
+                if (i == FM - 1) fb[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + sw);
+            } else {
+#pragma unroll
+                for (int u = 0; u < RPQ; ++u) {
+                    const int r = q * RPQ + u;
+                    if (r < FM) fa[1 - S][r] = *(const frag_ab*)(pa + r * 32 * 128 + sw);
+                    else if (r < NRD) fb[1 - S][r - FM] = *(const frag_ab*)(pb + (r - FM) * 32 * 128 + sw);
+                }
+            }
+            if constexpr (!CONV && !LW) {
+#pragma unroll
+                for (int u = 0; u < dpq; ++u) {
+                    const int r = q * dpq + u;
+                    if (r < RA && r < nd) blds16(rsA, aoff[r], (unsigned)dkt * (BK * 2), sA + slot_a(r) * 1024);
+                    else if (r < nd) blds16(rsW, woff[r - RA], (unsigned)dkt * (BK * 2), sA + A_TILE + slot_w(r - RA) * 1024);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one K-tile; MORE (compile time): tile kt + NS - 1 exists and this wave stages its share of it here.  (The convolution's
+    // gather recomputes per-lane offsets at tap boundaries behind a branch: its LDS-DMA instructions stay in front of the k-steps.)
+    auto ktile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value && !(ABL & 4) && !LW;
+        if constexpr (CONV && MORE) { stage(nxt, kt + NS - 1); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (!decltype(more_tag)::value) {   // residual rows of the epilogue: requested in front of the LAST K-tile
+            if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
+            if (kt == nk - 1 && wide_res) prefetch_residual_wide();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KPW - 1; ++kk)
+            kstep(kk & 1, cur, kk + 1, (kk == 0 && MORE && !CONV) ? L : 0, nxt, kt + NS - 1);
+        if constexpr (KPW == 1 && !CONV && MORE) { stage(nxt, kt + NS - 1); __builtin_amdgcn_sched_barrier(0); }
+        // every fragment of tile kt is in registers (its ring slot may be restaged after the barrier); tile kt + 1 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!LW) { if constexpr (MORE) wait_vmcnt<(NS - 2) * L>(); else { if (kt + 1 < nk) wait_vmcnt<0>(); } }
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        // (behind the last K-tile these reads fetch a stale ring slot into registers nobody uses: cheaper than a branch here)
+        kstep((KPW - 1) & 1, cur, 0, 0, 0, 0);
+    };
+    static_assert(KPW == 1 || ((KPW - 1) & 1) == 1, "the next tile's first fragments go to register set 0");
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) {
+        const int sw0 = ((k0 * 2 + lhi) ^ fsw) << 4;
+        if (r < FM) fa[0][r] = *(const frag_ab*)(smem + off_a + r * 32 * 128 + sw0);
+        else fb[0][r - FM] = *(const frag_ab*)(smem + off_b + (r - FM) * 32 * 128 + sw0);
     }
+    int kt = 0;
+    for (; kt + NS - 1 < nk; ++kt) ktile(kt, std::true_type{});
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{});
     }
 
     if constexpr (KS > 1) {
@@ -641,6 +695,14 @@ gemm_conv_kernel(const Params p) {
         __syncthreads();                               // the patches of the staged epilogue reuse this memory
     }
     if (prof_on) pt2 = prof_now();
+    if constexpr (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+        return;
+    }
     // ---------------------------------------------------------------- fused LayerNorm (consumer side), part 2
     // A was the raw row x; with W' = W*gamma:  Linear(LN(x))[m][n] = rstd_m * (acc[m][n] - mean_m * colsum_n) + t_n
     // (t_n arrives as the bias).  The rank-1 term -mean_m * colsum_n is one more MFMA k-step per fragment, fed from
@@ -1141,7 +1203,8 @@ struct TileCfg { int bm, bn; };
 // 16 = 256x256, 17 = 256x128 with the PHASE-OFFSET mainloop (PH: eight waves, K slices of 32 through a four-slot ring, the
 // second wave of every SIMD one barrier behind the first; GEMM only, no transposed region)
 // 18 = tiling 12 (128x160, 4-deep ring) with in-workgroup split-K over two wave groups (KS = 2): eight waves stage, GEMM only
-constexpr int NUM_CFG = 18;
+// 19 / 20 = tiling 12 (128x160, 4-deep ring) with one / two LOADER waves next to the four math waves (GEMM only)
+constexpr int NUM_CFG = 20;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 int launch_cfg(Params& p, int batch, hipStream_t st) {

@@ -560,9 +560,10 @@ class UNetPlan:
         return self._ln_buf[:pm * self.B * S * 2].view(pm, self.B * S, 2)
 
     def _link_ln(self):
+        for _i, kind, d in self._tunable:       # the tiling the library would substitute for a GEMM that leaves an e4m3 copy
+            if kind == "gemm" and (d.reserved0 & L.F8_COPY_OUT):
+                d.tile_cfg = L.F8COPY_TILE_ALT.get(d.tile_cfg, d.tile_cfg)
         for prod, cons in self._ln_links:
-            if (prod.reserved0 & L.F8_COPY_OUT) and prod.tile_cfg == 14:
-                prod.tile_cfg = 12          # the e4m3 copy is not compiled into 256x320; its stand-in writes another partial count
             parts = ops.stats_parts(prod.N, prod.tile_cfg)
             for c in cons:
                 c.ln_parts = parts
@@ -855,6 +856,38 @@ def refine_group(self, top=14, reps=9, verbose=False):
         base = best_t
     return base
 
+
+
+def _plans_of(plan):
+    return list(plan.plans) if hasattr(plan, "plans") else [plan]
+
+
+def used_tilings(plan):
+    """{"gemm:<TMIX_TILE id>": launches, "conv:<id>": launches} of a UNetPlan / PlanGroup as it will be launched (descriptor
+    values; fp8 launches and the F8-copy substitutions of gemm_conv.hip:launch are resolved by the library, the descriptor
+    holds the request).  bench.py prints it; the parity tests assert it for the plan they check against the oracle."""
+    out = {}
+    for p in _plans_of(plan):
+        for _i, kind, d in p._tunable:
+            k = f"{kind}:{d.tile_cfg}"
+            out[k] = out.get(k, 0) + 1
+    return dict(sorted(out.items()))
+
+
+def tilings_follow_table(plan):
+    """True when every tunable launch of the plan carries the tiling the SHIPPED table (tuned_gfx950.json) prescribes for its
+    shape and context -- i.e. nothing was re-tuned on this box, so a plan built here and one built by bench.py for the same
+    call run the same kernels.  Returns (ok, [(shape key, descriptor tiling, table tiling)] of the mismatches)."""
+    bad = []
+    for p in _plans_of(plan):
+        for _i, kind, d in p._tunable:
+            k = p._tune_key(kind, d)
+            want = tune_lookup(getattr(p, "tune_ctx", ""), k)
+            if kind == "gemm" and (d.reserved0 & L.F8_COPY_OUT):
+                want = L.F8COPY_TILE_ALT.get(want, want)
+            if want != d.tile_cfg:
+                bad.append((k, d.tile_cfg, want))
+    return not bad, bad
 
 
 class PlanGroup:
