@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--traj-cobatch", type=int, default=4, help="independent seeds sharing every UNet launch in the images/s measurement")
     ap.add_argument("--traj-images", type=int, default=8, help="images per rank in the images/s measurement (ignored with --num-seeds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-video", action="store_true", help="skip other_configs.video (BASELINE configs[4], one I2VGen-XL step)")
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--host-dry-run", action="store_true",
                     help="launcher / collective control flow only, on CPU over gloo with a stand-in step (tests; NOT a bench line)")
@@ -110,15 +111,15 @@ def timed_fusion_steps(tw, args, world, device, x):
     for i in range(max(args.warmup, 2)):        # the first call builds the plan, the second captures the graph
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -263,18 +264,20 @@ def gemm_alg_bytes(plan):
     return gb / max(1, len(plan.launches["gemm"]))
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
-    separate runs, FETCH doubled per MI355X_MICROARCH.md section HBM); collected by tools/collect_profile.sh with this
-    same workload, since counters cannot be read from inside the process.  None when no profile is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None
+def pmc_evidence():
+    """the committed rocprofv3 PMC passes this line cites, named by profiles/MANIFEST.json (not "whatever file sorts last"):
+    HBM bytes per GEMM launch (FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md section HBM) and the
+    time-weighted MfmaUtil per kernel class; collected by tools/collect_profile.sh with this same workload, since counters cannot be
+    read from inside the process.  Returns (traffic bytes or None, {"files": ..., "mfma_util_percent": ...})."""
+    man_path = os.path.join(ROOT, "profiles", "MANIFEST.json")
     try:
-        return float(json.load(open(files[-1]))["gemm"]["hbm_bytes_per_launch_corrected"])
-    except Exception:
-        return None
+        man = json.load(open(man_path))
+        tr = json.load(open(os.path.join(ROOT, "profiles", man["traffic"])))
+        traffic = float(tr["gemm"]["hbm_bytes_per_launch_corrected"])
+        mu = json.load(open(os.path.join(ROOT, "profiles", man["mfma_util"])))["per_kernel_class_time_weighted_percent"]
+        return traffic, {"files": man, "mfma_util_percent": mu}
+    except Exception as e:                    # no profile committed (or an unreadable one): say so instead of guessing
+        return None, {"files": None, "error": repr(e)}
 
 
 # ------------------------------------------------------------------------------------------------ trajectories
@@ -314,8 +317,15 @@ def run_trajectories(tw, args, rank, world, device):
     img = one.decode_final(lat)
     torch.cuda.synchronize()
     t_img = time.perf_counter() - t1
+    tv = time.perf_counter()
+    for _ in range(3):
+        one.decode_final(lat)
+    torch.cuda.synchronize()
+    vae_ms = 1e3 * (time.perf_counter() - tv) / 3
     assert torch.isfinite(img).all()
     calls = one.unet_calls[n_calls:]
+    out["vae_decode_ms"] = vae_ms
+    out["trajectory_steps_per_s"] = tw.config.n_timesteps / t_loop      # scheduler steps of one image per second, whole loop
     out["single_image"] = {"seconds_loop": t_loop, "seconds_incl_vae_decode": t_img, "unet_calls": len(calls),
                            "calls_BK1": sum(1 for c in calls if c[1] == K + 1), "calls_B2": sum(1 for c in calls if c[1] == 2)}
     del one
@@ -333,8 +343,8 @@ def run_trajectories(tw, args, rank, world, device):
     warm = co.run_fusion(noise(((batches[0] if batches else [0]) * C_)[:C_], tw.h, tw.w), decode=True)
     assert torch.isfinite(warm).all()
     torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
     t1 = time.perf_counter()
     lats = []
@@ -346,12 +356,13 @@ def run_trajectories(tw, args, rank, world, device):
     local = torch.cat(lats) if lats else torch.zeros(0, 4, tw.h, tw.w, device=device)
     torch.cuda.synchronize()
     assert torch.isfinite(local).all()
-    if world > 1 and args.num_seeds:                   # the result gather: the only collective of the path
+    if args.num_seeds:                                 # the result gather: the only collective of the path (a one-rank group at N = 1)
         gathered = D.gather_latents(local.contiguous(), total, rank, world)
         assert gathered.shape[0] == total and torch.isfinite(gathered).all()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
-    if world > 1:
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_backend() != "gloo":
         dt = D.max_over_ranks(dt, device)
     del co
     torch.cuda.empty_cache()
@@ -361,6 +372,65 @@ def run_trajectories(tw, args, rank, world, device):
                             f"decode, {C_} independent seeds per UNet launch"
                             + (" + RCCL all_gather of the latents" if world > 1 and args.num_seeds else "")})
     return out
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5
+def video_step_bench(steps=8, warmup=2, res_w=768, res_h=448, frames=16, streams=2):
+    """one denoising step of run_video.py's loop (/root/reference/video_gen/pipeline_i2vgen_xl.py:680-722): I2VGen-XL UNet on the
+    CFG pair of 16-frame 768x448 clips (2 x 16 x 56 x 96 latents; the two clips as two launch chains, run_video.py's default)
+    + the fused CFG / v-prediction / DDIM kernel, synthetic weights, one hipGraph per step.  Returns ms, steps/s, TFLOP/s."""
+    import numpy as np
+    from tweediemix_amd import i2vgen as I, ops
+    from tweediemix_amd.weights import synthetic_i2vgen_state_dict
+    h, w, Fr = res_h // 8, res_w // 8, frames
+    t0 = time.perf_counter()
+    sd = {k: v.to(torch.bfloat16) for k, v in synthetic_i2vgen_state_dict(I.FULL).items()}
+    Wt = I.I2VWeights(I.FULL, sd)
+    del sd
+    g = torch.Generator().manual_seed(0)
+    il = torch.randn(2, 4, Fr, h, w, generator=g)
+    fe, ctx, ilf = I.conditioning(Wt, torch.tensor([8.0, 8.0]), il, torch.randn(2, 1024, generator=g), torch.randn(2, 77, 1024, generator=g))
+    plan = (I.I2VPlanGroup if streams == 2 else I.I2VPlan)(Wt, 2, Fr, h, w, fe, ctx, ilf)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    x = torch.randn(1, 4, Fr, h, w, generator=g).cuda()
+    out = torch.empty_like(x)
+    acp = (np.cos((np.arange(1000) / 1000 + 0.008) / 1.008 * np.pi / 2) ** 2).astype(np.float32)
+    cin = I.FULL.in_channels
+
+    def step():
+        if streams == 2:
+            plan.set_input(x, 981)
+        else:
+            plan.x_in.view(2, Fr, 2 * cin, h, w)[:, :, :cin] = x.permute(0, 2, 1, 3, 4)
+            plan.t_dev.fill_(981.0)
+        plan.run()
+        v = plan.eps.view(2, Fr, I.FULL.out_channels, h, w).permute(0, 2, 1, 3, 4).contiguous()
+        ops.vpred_step(x, v, 9.0, acp[981], acp[961], out=out)
+        x.copy_(out)
+
+    step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t1) / steps
+    assert torch.isfinite(x).all()
+    res = {"workload": f"BASELINE configs[4]: I2VGen-XL (1.42 B parameters, synthetic), {frames} frames {res_w}x{res_h}, CFG pair = 2 clips, "
+                       f"{streams} launch chain(s), one denoising step = UNet + fused CFG/v-prediction/DDIM kernel, hipGraph replay",
+           "value": 1e3 / ms, "unit": "steps/s", "ms_per_step": ms, "unet_tflop_per_step": plan.flops / 1e12,
+           "achieved_tflops": plan.flops / ms / 1e9, "seconds_per_50_step_video": 50 * ms / 1e3, "launches_per_step": len(plan.ops),
+           "plan_build_s": build_s, "dtype": "bf16"}
+    del plan, Wt
+    torch.cuda.empty_cache()
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -392,14 +462,14 @@ def cpu_baseline(args, parts, K=3):
     t2 = call(2, small)
     traj = 27 * t4 + 18 * t2                 # config 1 = 27 calls at B=4 + 18 at B=2
     t1row = call(1, args.res)
-    return dict(value=1.0 / t4, unit="steps/s", cores=cores, kind="port",
-                sample=f"BASELINE config 1 shapes ({small}x{small}, K=3): one fusion-step UNet call at B={K + 1} ({t4:.1f}s) and one CFG-pair "
-                       f"call at B=2 ({t2:.1f}s), fp32 torch-CPU oracle, {cores} threads; value = fusion-phase steps/s at {small}^2 "
-                       f"(fused epilogue negligible); weight copy {prep:.1f}s not counted",
+    return dict(value=1.0 / ((K + 1) * t1row), unit="steps/s", cores=cores, kind="port",
+                sample=f"the headline workload ({args.res}x{args.res} fusion-phase step, UNet B={K + 1}): ONE of its {K + 1} batch rows through the fp32 "
+                       f"torch-CPU oracle ({t1row:.1f}s on {cores} threads); rows are independent, value = 1 / ({K + 1} x that) steps/s.  Also measured: "
+                       f"BASELINE config 1 ({small}x{small}): one B={K + 1} call {t4:.1f}s, one B=2 call {t2:.1f}s (see config1); weight copy {prep:.1f}s not counted",
                 config1={"resolution": small, "t_call_B4_s": t4, "t_call_B2_s": t2, "calls": "27 @B=4 + 18 @B=2",
                          "trajectory_s": traj, "trajectory_steps_per_s": 20.0 / traj},
-                extrapolated_1024={"steps_per_s": 1.0 / ((K + 1) * t1row), "t_one_row_s": t1row,
-                                   "how": f"1 of {K + 1} batch rows of the {args.res}x{args.res} fusion-step call; rows are independent, so steps/s = 1/((K+1)*t)"})
+                headline_row={"t_one_row_s": t1row, "rows": K + 1},
+                config1_steps_per_s=1.0 / t4)
 
 
 # ------------------------------------------------------------------------------------------------ dry run (CPU tests)
@@ -453,22 +523,30 @@ def main(argv=None):
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        if os.environ.get("TMIX_SINGLE_GPU_DIST_TEST"):
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+    import torch.distributed as dist
+    from tweediemix_amd import dist as D
+    # one process group per job -- ALSO at N = 1: RCCL is loaded, bound to this device, and carries the timing / gather collectives
+    backend = D.init(device, world, "gloo" if os.environ.get("TMIX_SINGLE_GPU_DIST_TEST") else None)
+    ranks_seen = D.ranks_seen(torch.device("cpu") if backend == "gloo" else device)
+    assert ranks_seen == world, (ranks_seen, world)
 
     primary = "lora" if args.kind in ("both", "lora") else "custom"
+    t_start = time.perf_counter()
     tw, parts = build_sampler(args, primary, device, seed=rank)       # each rank owns its own seeds (weak scaling)
+    torch.cuda.synchronize()
+    startup_s = time.perf_counter() - t_start                         # synthetic weights + per-concept LoRA merges + layout conversion, per rank
     K, S_ = tw.concept_num, args.seeds_per_gpu
     plan = tw.plan("fusion")
+    from tweediemix_amd import unet as U
+    # the timed plan runs the tilings of the SHIPPED table (nothing re-tuned on this box): the same assertion the oracle parity
+    # tests make for the plan they check (tests/test_unet_gpu.py::test_headline_size_timed_plan_graph_vs_fp32_oracle)
+    follows, bad = U.tilings_follow_table(plan)
+    assert follows or os.environ.get("TMIX_TUNE_FILE") is not None or args.tiny, f"timed plan deviates from the shipped tile table: {bad[:5]}"
+    tilings = {"used": U.used_tilings(plan), "follow_shipped_table": follows, "table": os.path.basename(U._TUNE_FILE) if U._TUNE_FILE else None}
+    plan_build_s = time.perf_counter() - t_start - startup_s
     x = torch.randn(S_, 4, tw.h, tw.w, generator=torch.Generator().manual_seed(1000 + rank)).to(device)
     dt, _x = timed_fusion_steps(tw, args, world, device, x)
-    if world > 1:
-        from tweediemix_amd import dist as D
-        dt = D.max_over_ranks(dt, device)
+    dt = D.max_over_ranks(dt, torch.device("cpu") if backend == "gloo" else device)      # through the group also at N = 1
     check = parity_check(tw, args, parts, primary, device)
     prof = insitu_profile(tw) if rank == 0 else None
     traj = None if args.no_trajectory else run_trajectories(tw, args, rank, world, device)
@@ -495,12 +573,15 @@ def main(argv=None):
                             "parity_check": parity_check(tw3, args, _parts3, primary, device)}
             del tw3
             torch.cuda.empty_cache()
+        if not args.tiny and not args.no_video:
+            other["video"] = video_step_bench()
     else:
         alg = gemm_alg_bytes(plan)
         flops_step = plan.flops
 
     if rank == 0:
         g = prof["gemm"]
+        pmc = pmc_evidence()
         line = {
             "metric": METRIC, "value": world * S_ * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / (args.steps * S_), "higher_is_better": True,
@@ -510,13 +591,19 @@ def main(argv=None):
                                    f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel, one hipGraph per step"
                                    + (" [TINY DEBUG CONFIG]" if args.tiny else ""),
                        "seeds_per_gpu": S_, "streams": args.streams, "hip_graph": not args.no_graphs,
-                       "parallelism": f"replicas x{world} (seed-sharded, no data-path collective)"},
+                       "parallelism": f"replicas x{world} (seed-sharded, no data-path collective)", "tilings": tilings},
+            "dist": {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": world, "ranks_seen": ranks_seen,
+                     "what": "ranks_seen = all-reduce of ones over the job's process group on the device; the step timing (MAX over ranks) and the "
+                             "trajectory latents go through the same group, also at N = 1",
+                     "startup_s_per_rank": startup_s, "plan_build_s": plan_build_s,
+                     "startup_what": "synthetic weight generation + per-concept LoRA merges + kernel-layout conversion on this rank's GPU (ranks start "
+                                     "concurrently, each on its own device: no shared host-side stage)"},
             "unet_tflop_per_step": flops_step / 1e12 / S_,
             "achieved_tflops_whole_step": flops_step / 1e12 / (dt / args.steps),
             "parity_check": check,
             "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<..,CONV=0> (tmix_gemm_bf16)",
                          "achieved": g["tflops"], "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": alg,
+                         "traffic": pmc[0], "pmc": pmc[1], "algorithmic_bytes_per_launch": alg,
                          "how": "achieved = sum(2MNK of the step's GEMM launches) / sum(their durations), each launch timed on the device clock "
                                 "INSIDE the captured step while the graph replays (concurrent chains included, so the sum can exceed the wall time)",
                          "launches_per_step": g["launches"], "avg_launch_us": g["avg_launch_us"], "flops_per_step": g["flops"],
@@ -527,13 +614,15 @@ def main(argv=None):
         }
         if traj is not None:
             line["images_per_s"] = traj["images_per_s"]
+            line["vae_decode_ms"] = traj["vae_decode_ms"]
+            line["trajectory_steps_per_s"] = traj["trajectory_steps_per_s"]
             line["trajectory"] = traj
         if other:
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, parts)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return 0
 

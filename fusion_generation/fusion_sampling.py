@@ -169,7 +169,9 @@ def main(argv=None):
     elif opt.random_masks or opt.synthetic:
         fg = None                                        # seeded rectangles, one set per trajectory seed (drawn when the sampler asks)
     else:   # the reference's file contract (:453-466): the side-car writes '<seg_concept>.jpg' under output_path
-        fg = [os.path.join(opt.output_path, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
+        # (several ranks: one side-car directory per rank, see masks.sidecar_layout)
+        side_dir, side_gpu = M.sidecar_layout(opt.output_path, rank, world, local, opt.seg_gpu)
+        fg = [os.path.join(side_dir, sp + '.jpg') for sp in opt.seg_concepts.split('+')]
         sidecar = True
     vae, vae_scaling = None, None
     vae_dir = opt.vae_path or (opt.sd_path and os.path.isdir(os.path.join(opt.sd_path, 'vae')) and os.path.join(opt.sd_path, 'vae'))
@@ -211,7 +213,7 @@ def main(argv=None):
         # with a VAE the whole contract runs like the reference: decode the Tweedie preview to {output_path}/tweedie.jpg,
         # call `CUDA_VISIBLE_DEVICES={seg_gpu} python text_segment/run_expand.py ...` (TMIX_SEG_CMD overrides the command),
         # read the masks back; without one the mask files must already be there
-        tw.mask_provider = M.SidecarMaskProvider(tw, opt.output_path, opt.seg_concepts, seg_gpu=opt.seg_gpu,
+        tw.mask_provider = M.SidecarMaskProvider(tw, side_dir, opt.seg_concepts, seg_gpu=side_gpu,
                                                  cmd_template=os.environ.get('TMIX_SEG_CMD'))
     lats, imgs = [], []
     for b0 in range(0, len(seeds), per):

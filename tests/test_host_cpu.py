@@ -249,3 +249,14 @@ def test_f8copy_layout():
     d.batch, d.M, d.N = 2, rows // 2, N
     cp.attach(d)
     assert d.Ct == cp.buf.data_ptr() and d.ldct == N and d.strideCt == cp.off and d.reserved0 == L.F8_COPY_OUT
+
+
+def test_sidecar_directories_do_not_collide_across_ranks():
+    """ranks sample different seeds concurrently: each runs its segmentation side-car in its own directory and not on a GPU
+    another rank samples on; a single process keeps the reference's paths (fusion_sampling.py:453-466)."""
+    from tweediemix_amd import masks as M
+    assert M.sidecar_layout("out", 0, 1, 0, 1) == ("out", 1)
+    dirs = [M.sidecar_layout("out", r, 4, r, 1) for r in range(4)]
+    assert len({d for d, _g in dirs}) == 4 and all(d.startswith("out") for d, _g in dirs)
+    assert [g for _d, g in dirs] == [0, 1, 2, 3]                    # --seg_gpu 1 is rank 1's GPU: every rank uses its own instead
+    assert M.sidecar_layout("out", 2, 4, 2, 6) == ("out/rank2", 6)  # a GPU outside the sampling ranks is honoured

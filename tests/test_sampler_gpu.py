@@ -437,3 +437,23 @@ def test_cli_sharded_seeds_equal_single_process_runs(tmp_path, monkeypatch):
         a = torch.load(tmp_path / "co" / f"p_{sd}.latent.pt")
         b = torch.load(tmp_path / "sharded" / f"p_{sd}.latent.pt")
         assert float((a - b).norm() / b.norm()) < 2e-2, sd
+
+
+def test_one_rank_rccl_group_carries_the_collectives():
+    """the `nccl` (= RCCL) branch on the one GPU a test box has: dist.init(device, world=1) binds a communicator to the device
+    (`device_id=`), ranks_seen / max_over_ranks / gather_latents run as device-side collectives -- in a child process, so the
+    test session's own (absent) process group is untouched."""
+    import subprocess
+    import sys
+    code = ("import torch, torch.distributed as dist\n"
+            "from tweediemix_amd import dist as D\n"
+            "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+            "assert D.init(dev, 1) == 'nccl' and dist.get_world_size() == 1 and D.ranks_seen(dev) == 1\n"
+            "x = torch.arange(5 * 4 * 8 * 8, dtype=torch.float32, device=dev).view(5, 4, 8, 8)\n"
+            "assert torch.equal(D.gather_latents(x, 5, 0, 1), x) and D.max_over_ranks(2.5, dev) == 2.5\n"
+            "dist.barrier(); dist.destroy_process_group(); print('RCCL_OK')\n")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-2000:]

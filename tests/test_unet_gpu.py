@@ -207,47 +207,76 @@ def _oracle_concepts(kind, con):
     return UO.Concepts("lora", lora=lo)
 
 
-@pytest.mark.parametrize("kind,hw", [("custom", 128), ("lora", 128), ("lora", 64)])
-def test_headline_size_plan_group_graph_vs_fp32_oracle(sdxl_weights, kind, hw):
-    """what bench.py times: SDXL shapes at latent 128x128 (1024x1024: S = 16384 / 4096 / 1024 tokens, 65,536-row convolutions),
-    B = K+1 = 4 concept-routed rows split into TWO launch chains on two streams (PlanGroup, the shipped `shared|` tile table),
-    captured into a hipGraph and replayed -- against the fp32 torch oracle on the same GPU.  `lora`: per-row merged weight sets
-    (strideW != 0) at the full 1280 width.  Tolerance as everywhere: rel L2 <= 2e-2, max-abs <= 5e-2 * max|ref|."""
-    from oracle import unet_oracle as UO
-    from tweediemix_amd import unet as U, weights as Wt
-    cfg, sd = U.SDXL, sdxl_weights
-    con = Wt.synthetic_concepts(cfg, kind, 3, device="cuda")
-    g = torch.Generator().manual_seed(5)
-    B, res = 4, hw * 8
-    ehs = torch.randn(B, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float()
-    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
-    tid = torch.tensor([[float(res), res, 0, 0, res, res]] * B)
-    x = torch.randn(1, 4, hw, hw, generator=g).repeat(B, 1, 1, 1).cuda()
+def _timed_plan(sd, kind, hw, streams, fp8=False):
+    """the fusion-phase UNet plan EXACTLY as bench.py's timed region builds it: bench.build_sampler's Tweediemix (same flags,
+    prompt rows uncond + K concepts, concept routing, `streams` launch chains, shipped tile table) -> tw.plan("fusion"), i.e.
+    sampler.Tweediemix._build_plan: one UNetPlan at B = 4 with routed row_sets for streams = 1 (the default), a PlanGroup of
+    two B = 2 chains for streams = 2.  Returns (plan, ehs, pooled, time_ids, concept state dicts)."""
+    from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
+    cfg, K = U.SDXL, 3
+    con = Wt.synthetic_concepts(cfg, kind, K, device="cuda")
     W = U.UNetWeights(cfg, sd, "cuda", (kind, con))
-    grp = U.PlanGroup(W, hw, hw, ehs, [0, 1, 2, 3], pooled, tid, True, 2)
-    assert all(p.routed == (kind == "lora") for p in grp.plans)
-    grp.latent.copy_(x)
-    grp.t_dev.fill_(601.0)
-    grp.run()                                            # warm-up outside capture
+    g = torch.Generator().manual_seed(5)
+    te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float(), torch.randn(K + 2, cfg.pooled_dim, generator=g))
+    ts = (torch.randn(K, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float(), torch.randn(K, cfg.pooled_dim, generator=g))
+    res = hw * 8
+    conf = S.make_config(guidance_scale=0.8, n_timesteps=50, t_cond=0.2, t_stop=0.8, resampling_steps=10, jumping_steps=5,
+                         resolution_h=res, resolution_w=res, seed=0)
+    tw = S.Tweediemix(conf, W, te, ts, lambda x0: M.build_masks(M.random_rectangle_masks(K, res, res, seed=1), hw, hw, "cuda"),
+                      concept_num=K, lora=(kind == "lora"), use_graphs=True, n_seeds=1, n_streams=streams, fp8=fp8)
+    tw.init_fusion(10, 40) if kind == "lora" else tw.init_fusion(10)
+    plan = tw.plan("fusion")
+    ehs = torch.cat([te[0][0:1], te[0][2:2 + K]])
+    pooled = torch.cat([te[1][0:1], te[1][2:2 + K]])
+    tid = tw.add_time_ids.repeat(K + 1, 1)
+    return plan, ehs, pooled, tid, con
+
+
+def _graph_replay(plan, x, t):
+    plan.latent.copy_(x)
+    plan.t_dev.fill_(float(t))
+    plan.run()                                           # warm-up outside capture
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
-        grp.run()
-    grp.eps.zero_()
+        plan.run()
+    plan.eps.zero_()
     gr.replay()
     torch.cuda.synchronize()
-    eps = grp.eps.clone()
-    ref = UO.UNetOracle(UO.SDXL, sd, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    return plan.eps.clone()
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+@pytest.mark.parametrize("kind,hw", [("custom", 128), ("lora", 128), ("lora", 64)])
+def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, streams):
+    """what bench.py TIMES, checked against the oracle: SDXL shapes at latent 128x128 (1024x1024: S = 16384 / 4096 / 1024 tokens,
+    65,536-row convolutions), B = K+1 = 4 concept-routed rows, built by the sampler's own plan builder (see _timed_plan) --
+    streams = 1: the DEFAULT one launch chain at the full batch (routed LoRA `row_sets`, un-prefixed tile-table entries);
+    streams = 2: two B = 2 chains on two streams (`shared|` entries) -- captured into a hipGraph and replayed, against the fp32
+    torch oracle on the same GPU.  The tilings are asserted to be the shipped table's (nothing re-tuned on this box), which is
+    what bench.py asserts for its timed plan too.  Tolerance as everywhere: rel L2 <= 2e-2, max-abs <= 5e-2 * max|ref|."""
+    from oracle import unet_oracle as UO
+    from tweediemix_amd import unet as U
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, kind, hw, streams)
+    assert isinstance(plan, U.PlanGroup) == (streams == 2)
+    assert all(p.routed == (kind == "lora") for p in U._plans_of(plan))
+    ok, bad = U.tilings_follow_table(plan)
+    assert ok, bad[:5]
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 4, hw, hw, generator=g).repeat(4, 1, 1, 1).cuda()
+    eps = _graph_replay(plan, x, 601)
+    ref = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
     torch.cuda.synchronize()
     r = rel_l2(eps, ref)
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
-    print(f"SDXL {kind} {res}^2 B=4, two chains, graph replay: rel_l2={r:.4g} max_rel={m:.4g}")
+    print(f"SDXL {kind} {hw * 8}^2 B=4, {streams} chain(s), graph replay: rel_l2={r:.4g} max_rel={m:.4g} tilings={U.used_tilings(plan)}")
     assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)
 
 
 def test_fp8_projections_tiny_unet_vs_oracle():
     """--dtype fp8 on the tiny UNet: attn1 q/k/v and both FF projections on e4m3 operands (tmix_gemm_fp8 behind one quantiser
-    launch each), everything else bf16 -- against the fp32 oracle.  States the cost: bf16 path ~4e-3, fp8 within 6e-2."""
+    launch each), everything else bf16 -- against the fp32 oracle.  States the cost: bf16 path ~4e-3, fp8 within 3e-2 (a 3-level toy network with 64-wide
+    rows has nothing to average the e4m3 rounding over; the SDXL-size test below holds the bf16 bound)."""
     from tweediemix_amd import unet as U
     orc, plan, x, ehs, pooled, tid = make("custom", 4, 16, 16, True)
     ref = orc.forward(x, 500, ehs, pooled, tid, routed=True)
@@ -256,34 +285,25 @@ def test_fp8_projections_tiny_unet_vs_oracle():
     got = p8(x.cuda(), 500).clone().cpu()
     r = rel_l2(got, ref)
     print(f"tiny UNet rel-L2 vs fp32 oracle: bf16 {base:.3e}, fp8 projections {r:.3e}")
-    assert torch.isfinite(got).all() and base <= 2e-2 and r <= 6e-2, (base, r)
+    assert torch.isfinite(got).all() and base <= 2e-2 and r <= 3e-2, (base, r)
 
 
-@pytest.mark.parametrize("kind", ["custom", "lora"])
-def test_fp8_projections_full_size_sdxl_vs_oracle(sdxl_weights, kind):
-    """the same at the real SDXL shapes (512 x 512, B = 4 routed rows, two chains): whole-UNet rel-L2 of the fp8 path vs the
-    fp32 oracle, measured and bounded (<= 8e-2; the bf16 path is bounded at 2e-2 by the tests above)."""
+@pytest.mark.parametrize("kind,hw", [("lora", 128), ("custom", 64)])
+def test_fp8_projections_full_size_sdxl_vs_oracle(sdxl_weights, kind, hw):
+    """the fp8 bench leg (`other_configs.fp8`: one chain at B = 4, latent 128 x 128, LoRA rows; and Custom-Diffusion rows at 64 x 64)
+    built by the sampler's own builder, hipGraph replay, vs the fp32 oracle.  Bound: whole-UNet rel-L2 <= 2e-2 -- the SAME bound as
+    the bf16 path (measured 5.4e-3 fp8 vs 5.3e-3 bf16: e4m3 operands with power-of-two block scales cost less than bf16 activations)."""
     from oracle import unet_oracle as UO
-    from tweediemix_amd import unet as U, weights as Wt
-    cfg, sd, hw = U.SDXL, sdxl_weights, 64
-    con = Wt.synthetic_concepts(cfg, kind, 3, device="cuda")
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, kind, hw, 1, fp8=True)
+    assert plan.fp8
     g = torch.Generator().manual_seed(6)
-    B, res = 4, hw * 8
-    ehs = torch.randn(B, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float()
-    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
-    tid = torch.tensor([[float(res), res, 0, 0, res, res]] * B)
-    x = torch.randn(1, 4, hw, hw, generator=g).repeat(B, 1, 1, 1).cuda()
-    W = U.UNetWeights(cfg, sd, "cuda", (kind, con))
-    grp = U.PlanGroup(W, hw, hw, ehs, [0, 1, 2, 3], pooled, tid, True, 2, fp8=True)
-    grp.latent.copy_(x)
-    grp.t_dev.fill_(601.0)
-    grp.run()
-    torch.cuda.synchronize()
-    eps = grp.eps.clone()
-    ref = UO.UNetOracle(UO.SDXL, sd, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    x = torch.randn(1, 4, hw, hw, generator=g).repeat(4, 1, 1, 1).cuda()
+    eps = _graph_replay(plan, x, 601)
+    ref = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
     r = rel_l2(eps, ref)
-    print(f"SDXL {kind} {res}^2 B=4 fp8 projections: rel_l2={r:.4g}")
-    assert torch.isfinite(eps).all() and r <= 8e-2, r
+    m = (eps - ref).abs().max().item() / ref.abs().max().item()
+    print(f"SDXL {kind} {hw * 8}^2 B=4 fp8 projections, one chain, graph replay: rel_l2={r:.4g} max_rel={m:.4g}")
+    assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)
 
 
 def test_real_checkpoint_activation_statistics_if_available():

@@ -29,6 +29,30 @@ def test_vae_decoder_matches_oracle(B, h, w, inv):
     assert ref.std().item() > 0.05          # the test image is not a constant (clamp did not flatten it)
 
 
+def test_full_size_vae_decode_1024_in_groups_vs_oracle():
+    """what `images_per_s` / the CLI's final decode run: the FULL SDXL VAE decoder (49.5 M parameters) at latent 128 x 128
+    (1024 x 1024 pixels: a 16,384-token d = 512 attention through fp32-score GEMMs, [n,1024,1024,128] activations), through
+    vae.decode_in_groups with FOUR latents -- one plan of three images plus one of a single image, the grouping sampler._decode
+    applies to co-batched seeds -- against the fp32 torch oracle evaluated on the same GPU, image by image."""
+    from oracle import vae_oracle as VO
+    from tweediemix_amd import vae as V
+    sd = V.synthetic_state_dict(V.FULL, nontrivial=True)
+    assert sum(v.numel() for k, v in sd.items() if not k.startswith("encoder.")) == 49_490_199
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(4, 4, 128, 128, generator=g) * 0.13025 * 3).cuda()
+    plans = {}
+    img = V.decode_in_groups((V.FULL, sd), z, 1 / 0.13025, plans).float().cpu()
+    assert sorted(k[1] for k in plans) == [1, 3], "four 1024^2 images decode as a group of three and a group of one"
+    orc = VO.VAEDecoderOracle(VO.FULL, {k: v.cuda() for k, v in sd.items()})
+    for i in range(4):
+        ref = orc.decode(z[i:i + 1], 1 / 0.13025).cpu()
+        err = (img[i:i + 1] - ref).abs().max().item()
+        rel = ((img[i:i + 1] - ref).norm() / ref.norm()).item()
+        print(f"full VAE decode 1024^2 image {i}: max abs {err:.4g} rel L2 {rel:.4g} (image std {ref.std().item():.3f})")
+        assert img[i:i + 1].shape == ref.shape == (1, 3, 1024, 1024) and err <= 2e-2 and rel <= 2e-2, (i, err, rel)
+        assert ref.std().item() > 0.05
+
+
 def test_softmax_rows_and_f32_gemm():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")

@@ -77,6 +77,18 @@ def expand_masks(masks):
     return rect
 
 
+def sidecar_layout(output_path, rank: int, world: int, local_gpu: int, seg_gpu: int):
+    """(directory, GPU) the segmentation side-car of rank `rank` uses.  One process (the reference's mode): exactly the reference's
+    `{output_path}` and `--seg_gpu`.  Several ranks sample different seeds at the same time, so each gets its OWN directory
+    `{output_path}/rank{r}` -- with a shared one, rank A could read the masks the side-car wrote for rank B's preview -- and, when
+    `--seg_gpu` names a GPU that one of the ranks samples on (the default 1 does as soon as world > 1), the side-car runs on the
+    rank's own GPU instead: that GPU is idle while its rank waits for the masks, whereas another rank's GPU is mid-trajectory."""
+    import os
+    if world <= 1:
+        return output_path, seg_gpu
+    return os.path.join(output_path, f"rank{rank}"), (local_gpu if 0 <= seg_gpu < world else seg_gpu)
+
+
 class SidecarMaskProvider:
     """The reference's segmentation side-car contract (fusion_sampling.py:453-469): decode the Tweedie preview,
     save `{output_path}/tweedie.jpg`, run an external command that writes `{output_path}/{seg_concept}.jpg`
@@ -94,6 +106,7 @@ class SidecarMaskProvider:
         import os
         from PIL import Image
         os.makedirs(self.output_path, exist_ok=True)
+        assert x0_preview.shape[0] == 1, "one preview per call: the sampler asks once per co-batched seed, in seed order"
         img = self.sampler.decode_latent(x0_preview[:1])[0]                       # [3,H,W] in [0,1]
         arr = (img.clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()   # ToPILImage semantics (mul 255, byte)
         path = os.path.join(self.output_path, "tweedie.jpg")

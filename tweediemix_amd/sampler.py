@@ -262,21 +262,10 @@ class Tweediemix:
 
     # ------------------------------------------------------------------ VAE
     def _decode(self, latent, inv_scale):
-        from .vae import VAEDecoderPlan
         if self.vae is None:
             raise L.TmixError("no VAE weights were given to Tweediemix(vae=(config, state_dict))")
-        # the decoder's largest activation is [n, 8h, 8w, 256] bf16: the conv kernel's 32-bit element offsets (< 2^30) hold two
-        # 1024 x 1024 images, so co-batched latents are decoded in groups
-        per = max(1, min(latent.shape[0], (1 << 30) // max(1, 64 * self.h * self.w * 256 + 1)))
-        outs = []
-        for i in range(0, latent.shape[0], per):
-            part = latent[i:i + per]
-            key = (round(inv_scale, 6), part.shape[0])
-            if key not in self._vae_plans:
-                self._vae_plans[key] = VAEDecoderPlan(self.vae[0], self.vae[1], part.shape[0], self.h, self.w, inv_scale, self.device)
-            y = self._vae_plans[key](part)
-            outs.append(y if latent.shape[0] <= per else y.clone())
-        return outs[0] if len(outs) == 1 else torch.cat(outs)
+        from .vae import decode_in_groups
+        return decode_in_groups(self.vae, latent, inv_scale, self._vae_plans, self.device)
 
     @torch.no_grad()
     def decode_latent(self, latent):

@@ -879,10 +879,21 @@ def tilings_follow_table(plan):
     shape and context -- i.e. nothing was re-tuned on this box, so a plan built here and one built by bench.py for the same
     call run the same kernels.  Returns (ok, [(shape key, descriptor tiling, table tiling)] of the mismatches)."""
     bad = []
+    with open(_TUNE_FILE) as f:                 # the FILE, not the process cache (which also holds shapes timed on this box)
+        table = {k: int(v) for k, v in json.load(f).items()}
+
+    def shipped(ctx, key):
+        c = table.get(ctx + key)
+        if c is None and ctx:
+            c = table.get(key)
+            if c in L.TILE_EXCLUSIVE:
+                c = None
+        return c
+
     for p in _plans_of(plan):
         for _i, kind, d in p._tunable:
             k = p._tune_key(kind, d)
-            want = tune_lookup(getattr(p, "tune_ctx", ""), k)
+            want = shipped(getattr(p, "tune_ctx", ""), k)
             if kind == "gemm" and (d.reserved0 & L.F8_COPY_OUT):
                 want = L.F8COPY_TILE_ALT.get(want, want)
             if want != d.tile_cfg:

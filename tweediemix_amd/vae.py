@@ -272,6 +272,24 @@ class VAEDecoderPlan:
         return self.image
 
 
+def decode_in_groups(vae, latent, inv_scale, plans, device="cuda"):
+    """decode `latent` [n,4,h,w] with VAEDecoderPlan(s) cached in `plans`.  The decoder's largest activation is
+    [n, 8h, 8w, 256] bf16 and the conv kernel's element offsets are 32-bit (< 2^30), so co-batched latents are decoded in
+    groups (three 1024 x 1024 images per plan) -- fusion_sampling.py:496-528 decodes its single latent in one call."""
+    cfg, sd = vae
+    h, w = latent.shape[-2:]
+    per = max(1, min(latent.shape[0], (1 << 30) // max(1, 64 * h * w * 256 + 1)))
+    outs = []
+    for i in range(0, latent.shape[0], per):
+        part = latent[i:i + per]
+        key = (round(inv_scale, 6), part.shape[0], h, w)
+        if key not in plans:
+            plans[key] = VAEDecoderPlan(cfg, sd, part.shape[0], h, w, inv_scale, device)
+        y = plans[key](part)
+        outs.append(y if latent.shape[0] <= per else y.clone())
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+
 class VAEEncoderPlan(VAEDecoderPlan):
     """encode(image [B,3,H,W] fp32 in [-1,1]) -> (mean, logvar) [B,4,H/8,W/8] fp32 of AutoencoderKL.encode (the I2VGen-XL pipeline's
     `prepare_image_latents`, video_gen/pipeline_i2vgen_xl.py:421-451, samples from it and scales by 0.18215).  Same emitters as the
