@@ -518,6 +518,11 @@ def main(argv=None):
     rank, local, world = LA.rank_env()
     if args.host_dry_run:
         return host_dry_run(args, rank, world)
+    # stdout carries exactly ONE line, the JSON: everything else this process (or a library under it -- RCCL prints a version
+    # banner through C stdio when its first communicator comes up) writes to file descriptor 1 goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     if os.environ.get("TMIX_SINGLE_GPU_DIST_TEST"):     # debug only: all ranks share GPU 0 over gloo (control-flow test)
         local = 0
@@ -621,7 +626,7 @@ def main(argv=None):
             line["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, parts)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0

@@ -3,7 +3,7 @@
 // Replaces the explicit softmax(QK^T)V of utils_custom.py:93-103 / utils_lora.py:101-111 (which
 // materialises [B*heads, S, S]) and xformers' attn1 kernel.  One workgroup = 4 waves = 128 query rows
 // of one (batch, head); K and V^T tiles of 64 keys are staged HBM->LDS by LDS-DMA (global_load_lds,
-// double buffered, XOR-swizzled through the source address) and shared by the 4 waves.
+// a ring of four tiles, XOR-swizzled through the source address) and shared by the 4 waves.
 //
 // Register-only softmax: the scores are computed TRANSPOSED, S^T = K Q^T (MFMA A operand = K rows,
 // B operand = Q rows), so a lane holds 4 keys x 1 query per 16x16 fragment and the row reductions
@@ -20,6 +20,13 @@
 
 namespace {
 
+// TMIX_ATTN_ABL (dev builds under tools/ab/ only): ablations that locate the bound of the tile loop -- bit 0: no exp2 (a multiply
+// instead), bit 1: no PV / row-sum MFMAs, bit 2: no QK^T MFMAs, bit 3: no LDS-DMA inside the loop (the ring is re-read), bit 4: no maximum test per tile.
+#ifndef TMIX_ATTN_ABL
+#define TMIX_ATTN_ABL 0
+#endif
+constexpr int AABL = TMIX_ATTN_ABL;
+
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
@@ -27,8 +34,6 @@ constexpr int QB = 128;          // query rows per 4-wave workgroup (32 per wave
 constexpr int KB = 64;           // keys per tile
 constexpr int TILE = KB * 64 * 2;    // 8 KiB (K tile or V^T tile)
 constexpr int STAGE = 2 * TILE;
-constexpr int NS = 3;                // LDS ring depth: NS-1 tiles requested ahead, NS-2 in flight across a barrier
-constexpr int SMEM = NS * STAGE;     // 48 KiB -> 3 workgroups per CU
 
 struct AttnParams {
     const bf16_t* Q; int64_t ldq, strideQ;
@@ -71,13 +76,19 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     return *(uint32_t*)&v;
 }
 
-// NWV = 4 (default): 128 query rows per workgroup, two workgroups per CU.  NWV = 8: 256 rows, ONE workgroup per CU -- the same
-// eight waves per CU, a K / V^T tile staged once for 256 queries instead of twice for 2 x 128 (half the LDS-DMA instructions
-// per wave, half the L2 -> LDS traffic) -- but slower in situ, see tmix_attn_fwd.
-template <int NWV>
-__global__ void __launch_bounds__(NWV * 64, 2) attn_fwd_kernel(const AttnParams p) {
-    constexpr int LOADS = 16 / NWV;      // LDS-DMA instructions per wave per tile (16 KiB tile, 1 KiB per instruction)
-    constexpr int NR = 8 / NWV;          // staging rounds per wave and operand
+// ---- self-attention, software-pipelined over KV tiles.
+// Round 2's kernel ran a tile as QK^T MFMAs -> softmax VALU -> PV MFMAs, each stage waiting for the one before (matrix pipe ~25 %
+// busy; ablations: tools/jobs/r3j_attn_abl.sh, r3m.sh).  Here one loop iteration works on TWO tiles: the QK^T MFMAs of tile t are issued with the exp2 / bf16-pack arithmetic of
+// tile t-1 between them (one packed word = two exp2 + one convert behind every MFMA), and the PV MFMAs of tile t-1 with the
+// maximum search of tile t between them -- MFMAs execute asynchronously, so the VALU work rides in their shadow inside ONE wave.
+// The barrier that hands over tile t+1 sits between the two halves; the K fragments of tile t+1 and the LDS-DMA of tile t+3
+// are requested under the PV MFMAs, the V^T fragments of tile t-1 under the QK^T MFMAs.  Ring of 4 tiles (t-1 .. t+2), 64 KiB.
+constexpr int NSP = 4;
+constexpr int SMEM_P = NSP * STAGE;
+
+__global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams p) {
+    constexpr int LOADS = 4;             // LDS-DMA instructions per wave per tile (16 KiB tile, 1 KiB per instruction)
+    constexpr int NR = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,194 +100,220 @@ __global__ void __launch_bounds__(NWV * 64, 2) attn_fwd_kernel(const AttnParams 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = bid / p.nq, qt = bid - bh * p.nq;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qt * (NWV * 32) + w * 32;
-
+    const int q0 = qt * QB + w * 32;
     const bf16_t* Qb = p.Q + (int64_t)b * p.strideQ + h * 64;
     const bf16_t* Kb = p.K + (int64_t)b * p.strideK + h * 64;
     const bf16_t* Vb = p.Vt + (int64_t)b * p.strideVt + (int64_t)h * 64 * p.ldvt;
 
-    // ---- Q fragments (B operand of S^T = K Q^T), kept in registers for the whole kernel
+    // ---- staging: per wave 2 rounds x (8 rows x 8 chunks) for K and for V^T, XOR-swizzled through the source address
+    const int lrow = lane >> 3;
+    const int schunk = ((lane & 7) ^ lrow) * 8;
+    int krow[NR], voff[NR];
+    const int ldk = (int)p.ldk, ldvt = (int)p.ldvt;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int rho = (r * 4 + w) * 8 + lrow;            // LDS row 0..63
+        const int f = rho >> 4, i = rho & 15;
+        krow[r] = 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3);
+        voff[r] = rho * ldvt;
+    }
+    const int nt = (p.Skv + KB - 1) / KB;
+    auto stage = [&](int t) {
+        char* sK = smem + (t & (NSP - 1)) * STAGE;
+        char* sV = sK + TILE;
+        const int kv0 = t * KB;
+        int c = kv0 + schunk; if (c > ldvt - 8) c = ldvt - 8;       // fully masked chunk: any finite data
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int off = (r * 4 + w) * 1024;
+            int key = kv0 + krow[r]; if (key > p.Skv - 1) key = p.Skv - 1;
+            glds16(Kb + (unsigned)(key * ldk + schunk), sK + off);
+            glds16(Vb + (unsigned)(voff[r] + c), sV + off);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NSP - 1; ++t)
+        if (t < nt) stage(t);
+
+    // ---- Q fragments (B operand of S^T = K Q^T), scale * log2(e) folded in; loaded while the first tiles are in flight
     frag_ab qf[2][2];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         int q = q0 + qi * 16 + fr; if (q > p.Sq - 1) q = p.Sq - 1;
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
-            // fold softmax scale * log2(e) into Q once (one extra bf16 rounding of q, none per score)
             const frag_ab raw = *(const frag_ab*)(Qb + (int64_t)q * p.ldq + ds * 32 + fg * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[qi][ds][j] = (__bf16)((float)raw[j] * p.scale_log2e);
         }
     }
 
-    // ---- staging geometry: per wave 2 rounds x (8 rows x 8 chunks) for K and for V^T
-    const int lrow = lane >> 3;
-    const int schunk = ((lane & 7) ^ lrow) * 8;
-    int krow[NR];                      // key (within tile) whose row lands in this lane's LDS row
-    int vrow[NR];                      // d row of V^T
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int rho = (r * NWV + w) * 8 + lrow;          // LDS row 0..63
-        const int f = rho >> 4, i = rho & 15;
-        krow[r] = 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3);
-        vrow[r] = rho;
-    }
-    const int nt = (p.Skv + KB - 1) / KB;
-    // per-lane source offsets stay 32-bit (elements); the 64-bit bases are wave-uniform
-    const int ldk = (int)p.ldk, ldvt = (int)p.ldvt;
-    int voff[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) voff[r] = vrow[r] * ldvt;
-    auto stage = [&](int buf, int t) {
-        char* sK = smem + buf * STAGE;
-        char* sV = sK + TILE;
-        const int kv0 = t * KB;
-        int c = kv0 + schunk; if (c > ldvt - 8) c = ldvt - 8;       // fully masked chunk: any finite data
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int off = (r * NWV + w) * 1024;
-            int key = kv0 + krow[r]; if (key > p.Skv - 1) key = p.Skv - 1;
-            glds16(Kb + (unsigned)(key * ldk + schunk), sK + off);
-            glds16(Vb + (unsigned)(voff[r] + c), sV + off);
-        }
-    };
-
-    f32x4 o[4][2];                     // O^T accumulators: [d fragment][q fragment]
+    f32x4 o[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    // one KV tile: S^T = K Q^T (already in log2 units, accumulated on top of -m so the MFMA does the subtraction),
-    // P = exp2(S^T), O^T += V^T P^T.  The running maximum m is only moved when some score exceeds it by more than
-    // THR (deferred rescale, P <= 2^THR stays well inside bf16/fp32 range), so the common path has no cross-lane
-    // traffic, no per-score subtract and no accumulator rescale.  MASK = tile holds keys >= Skv.
     constexpr float THR = 8.0f;
-    f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // -m per query column, replicated for the MFMA C operand
-    f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // softmax denominators, accumulated BY THE MATRIX CORE
-    frag_ab ones;                                                     // A operand of all 1.0: D[i][q] = sum_k P^T[k][q]
+    f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    frag_ab ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     bool first = true;
-    auto tile = [&](int cur, int kv0, auto mask_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
-        const char* sK = smem + cur * STAGE;
-        const char* sV = sK + TILE;
-        f32x4 s[4][2];
-        {
-            const int sw0 = ((0 * 4 + fg) ^ (fr & 7)) << 4, sw1 = ((1 * 4 + fg) ^ (fr & 7)) << 4;
+
+    frag_ab kf[2][4];                  // K fragments of the tile whose QK^T comes next: [d half][key fragment]; half 0 is read
+                                       // under the previous PV MFMAs, half 1 under the first QK^T MFMAs (16 registers fewer across the barrier)
+    frag_ab vf[2][4];                  // V^T fragments of the tile whose PV comes next: [k-step][d fragment]
+    uint32_t pb[2][2][4];              // packed P^T of that tile: [qi][k-step] = B operand of O^T = V^T P^T
+    const int swk0 = ((0 * 4 + fg) ^ (fr & 7)) << 4, swk1 = ((1 * 4 + fg) ^ (fr & 7)) << 4;
+    auto read_k = [&](int t) {
+        const char* sK = smem + (t & (NSP - 1)) * STAGE;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const frag_ab k0 = *(const frag_ab*)(sK + (f * 16 + fr) * 128 + sw0);
-                s[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0][0], negm[0], 0, 0, 0);
-                s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[1][0], negm[1], 0, 0, 0);
-            }
+        for (int f = 0; f < 4; ++f) kf[0][f] = *(const frag_ab*)(sK + (f * 16 + fr) * 128 + swk0);
+    };
+
+    // first half of an iteration: QK^T of tile t into sc (CUR) with exp2 + pack of tile t-1 (sp -> pb) and its V^T fragment reads
+    // spread between the MFMAs (PREV); issue order pinned
+    auto half1 = [&](int t, f32x4 (&sc)[4][2], f32x4 (&sp)[4][2], auto cur_tag, auto prev_tag) {
+        constexpr bool CUR = decltype(cur_tag)::value, PREV = decltype(prev_tag)::value;
+        const char* sV = smem + ((t - 1) & (NSP - 1)) * STAGE + TILE;
+        const char* sKc = smem + (t & (NSP - 1)) * STAGE;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const frag_ab k1 = *(const frag_ab*)(sK + (f * 16 + fr) * 128 + sw1);
-                s[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[0][1], s[f][0], 0, 0, 0);
-                s[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1][1], s[f][1], 0, 0, 0);
+        for (int n = 0; n < 16; ++n) {
+            // MFMA n: d half n >> 3, key fragment (n >> 1) & 3, query fragment n & 1   (the two d halves of a score are 8 MFMAs apart)
+            const int dh = n >> 3, f = (n >> 1) & 3, qi = n & 1;
+            if constexpr (CUR) {
+                if constexpr (AABL & 4) { if (dh == 0) sc[f][qi] = negm[qi]; asm volatile("" :: "v"(kf[dh][f])); }
+                else sc[f][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[dh][f], qf[qi][dh], dh ? sc[f][qi] : negm[qi], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CUR) { if (n < 4) kf[1][n] = *(const frag_ab*)(sKc + (n * 16 + fr) * 128 + swk1); }
+            if constexpr (PREV) {
+                // packed word n of P^T(t-1): scores (f, qi, 2 hh) and (f, qi, 2 hh + 1) with f = n >> 2, qi = (n >> 1) & 1, hh = n & 1
+                const int pf = n >> 2, pq = (n >> 1) & 1, hh = n & 1;
+                const float e0 = (AABL & 1) ? sp[pf][pq][2 * hh] * 0.001f : __builtin_amdgcn_exp2f(sp[pf][pq][2 * hh]);
+                const float e1 = (AABL & 1) ? sp[pf][pq][2 * hh + 1] * 0.001f : __builtin_amdgcn_exp2f(sp[pf][pq][2 * hh + 1]);
+                pb[pq][pf >> 1][(pf & 1) * 2 + hh] = pk_bf16(e0, e1);
+                asm volatile("" : "+v"(pb[pq][pf >> 1][(pf & 1) * 2 + hh]));      // computed HERE (LLVM otherwise sinks it to its first use, behind the barrier)
+                if (n >= 4 && n < 12) { const int m = n - 4; vf[m >> 2][m & 3] = *(const frag_ab*)(sV + ((m & 3) * 16 + fr) * 128 + ((((m >> 2) * 4 + fg) ^ (fr & 7)) << 4)); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (MASK) {
+    };
+    // second half: PV (and row sums) of tile t-1 (PREV) with the maximum search of tile t (CUR) between the MFMAs; the K fragments
+    // of tile t+1 are requested here too.  Then, rarely, the running maximum moves (deferred rescale: P <= 2^THR stays well inside bf16 / fp32 range).
+    auto half2 = [&](int t, f32x4 (&sc)[4][2], auto cur_tag, auto prev_tag, auto mask_tag) {
+        constexpr bool CUR = decltype(cur_tag)::value, PREV = decltype(prev_tag)::value, MASK = decltype(mask_tag)::value;
+        if constexpr (CUR && MASK) {
+            const int kv0 = t * KB;
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) s[f][qi][r] = -INFINITY;
+                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) sc[f][qi][r] = -INFINITY;
         }
-        // threshold test on the raw bit patterns: for "is any score > THR (> 0)" signed-integer order equals float
-        // order (negative floats are negative ints), and integer max needs no IEEE canonicalisation of MFMA outputs.
         int im = 0x80000000;
+        const char* sKn = smem + ((t + 1) & (NSP - 1)) * STAGE;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-                im = max(max(im, max(__float_as_int(s[f][qi][0]), __float_as_int(s[f][qi][1]))),
-                         max(__float_as_int(s[f][qi][2]), __float_as_int(s[f][qi][3])));
-        if (first || __any(im > __float_as_int(THR))) {
-            // move the maximum: delta = row max relative to the old m (over all 4 lane groups of the column)
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                float m0 = fmaxf(fmaxf(s[0][qi][0], s[0][qi][1]), fmaxf(s[0][qi][2], s[0][qi][3]));
-#pragma unroll
-                for (int f = 1; f < 4; ++f) m0 = fmaxf(fmaxf(m0, fmaxf(s[f][qi][0], s[f][qi][1])), fmaxf(s[f][qi][2], s[f][qi][3]));
-                float delta = xor32_max(xor16_max(m0));
-                if (!first) delta = fmaxf(delta, 0.f);               // never lower an established maximum
-                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) s[f][qi] = s[f][qi] - delta;
-#pragma unroll
-                for (int df = 0; df < 4; ++df) o[df][qi] *= alpha;
-                lacc[qi] *= alpha;
-                negm[qi] = negm[qi] - delta;
+        for (int n = 0; n < 20; ++n) {
+            if constexpr (PREV) {
+                const int ps = n / 10, m = n % 10;       // per k-step: two row-sum MFMAs, then 4 d fragments x 2 query fragments
+                frag_ab p0, p1;
+                __builtin_memcpy(&p0, pb[0][ps], 16);
+                __builtin_memcpy(&p1, pb[1][ps], 16);
+                if constexpr (AABL & 2) asm volatile("" :: "v"(p0), "v"(p1), "v"(vf[ps][(m >> 1) & 3]));
+                else if (m == 0) lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, lacc[0], 0, 0, 0);
+                else if (m == 1) lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, lacc[1], 0, 0, 0);
+                else if (m & 1) o[(m - 2) >> 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ps][(m - 2) >> 1], p1, o[(m - 2) >> 1][1], 0, 0, 0);
+                else o[(m - 2) >> 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ps][(m - 2) >> 1], p0, o[(m - 2) >> 1][0], 0, 0, 0);
             }
-            first = false;
-        }
-        uint32_t pb[2][2][4];          // [qi][k-step] packed bf16x8 = B operand of O^T = V^T P^T
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[f][qi][r] = __builtin_amdgcn_exp2f(s[f][qi][r]);
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                pb[qi][ps][0] = pk_bf16(s[2 * ps][qi][0], s[2 * ps][qi][1]);
-                pb[qi][ps][1] = pk_bf16(s[2 * ps][qi][2], s[2 * ps][qi][3]);
-                pb[qi][ps][2] = pk_bf16(s[2 * ps + 1][qi][0], s[2 * ps + 1][qi][1]);
-                pb[qi][ps][3] = pk_bf16(s[2 * ps + 1][qi][2], s[2 * ps + 1][qi][3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CUR) {
+                if (n < 8) {           // integer order = float order for "is any score > THR (> 0)"
+                    const int f = n >> 1, qi = n & 1;
+                    im = max(max(im, max(__float_as_int(sc[f][qi][0]), __float_as_int(sc[f][qi][1]))),
+                             max(__float_as_int(sc[f][qi][2]), __float_as_int(sc[f][qi][3])));
+                } else if (n < 12) {   // K fragments (first d half) of the next tile (a stale slot behind the last tile: never used)
+                    kf[0][n - 8] = *(const frag_ab*)(sKn + ((n - 8) * 16 + fr) * 128 + swk0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (CUR) {
+            if ((AABL & 16) ? first : (first || __any(im > __float_as_int(THR)))) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int sw = ((ps * 4 + fg) ^ (fr & 7)) << 4;
-            frag_ab p0, p1;
-            __builtin_memcpy(&p0, pb[0][ps], 16);
-            __builtin_memcpy(&p1, pb[1][ps], 16);
-            // row sums of the bf16-rounded P (exactly what multiplies V): one MFMA per (k-step, query fragment)
-            lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, lacc[0], 0, 0, 0);
-            lacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, lacc[1], 0, 0, 0);
+                for (int qi = 0; qi < 2; ++qi) {
+                    float m0 = fmaxf(fmaxf(sc[0][qi][0], sc[0][qi][1]), fmaxf(sc[0][qi][2], sc[0][qi][3]));
 #pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const frag_ab vf = *(const frag_ab*)(sV + (df * 16 + fr) * 128 + sw);
-                o[df][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p0, o[df][0], 0, 0, 0);
-                o[df][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p1, o[df][1], 0, 0, 0);
+                    for (int f = 1; f < 4; ++f) m0 = fmaxf(fmaxf(m0, fmaxf(sc[f][qi][0], sc[f][qi][1])), fmaxf(sc[f][qi][2], sc[f][qi][3]));
+                    float delta = xor32_max(xor16_max(m0));
+                    if (!first) delta = fmaxf(delta, 0.f);               // never lower an established maximum
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) sc[f][qi] = sc[f][qi] - delta;
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) o[df][qi] *= alpha;
+                    lacc[qi] *= alpha;
+                    negm[qi] = negm[qi] - delta;
+                }
+                first = false;
             }
         }
     };
+    // hand-over between the halves of iteration t: this wave's LDS reads are in registers, tile t+1 has landed for everybody,
+    // tile t-1's ring slot is free -> tile t+3 is requested into it
+    auto sync = [&](int t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 2 < nt) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (!(AABL & 8) && t + 3 < nt) stage(t + 3);
+    };
 
-    // K/V tiles are small (16 KiB) and a tile's compute is shorter than the L2->LDS latency, so the loop keeps
-    // NS-2 tiles in flight across each barrier (counted vmcnt + raw s_barrier, as in the GEMM mainloop).
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nt) stage(s, s);
-    if (nt >= NS - 1) wait_vmcnt<(NS - 2) * LOADS>(); else wait_vmcnt<0>();
+    f32x4 sA[4][2], sB[4][2];
+    const bool tail_masked = (p.Skv % KB) != 0;
+    using T_ = std::true_type; using F_ = std::false_type;
+    if (nt >= NSP - 1) wait_vmcnt<(NSP - 2) * LOADS>(); else if (nt == 2) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (prof_on) pt1 = prof_now();
-    int cur = 0, nxt = NS - 1;
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + NS - 1 < nt;
-        if (more) stage(nxt, t + NS - 1);
-        const int kv0 = t * KB;
-        if (kv0 + KB > p.Skv) tile(cur, kv0, std::true_type{});
-        else                  tile(cur, kv0, std::false_type{});
-        if (more) wait_vmcnt<(NS - 2) * LOADS>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    read_k(0);
+    // iteration 0 has no previous tile
+    half1(0, sA, sB, T_{}, F_{});
+    sync(0);
+    if (nt == 1 && tail_masked) half2(0, sA, T_{}, F_{}, T_{}); else half2(0, sA, T_{}, F_{}, F_{});
+    int t = 1;
+    for (; t + 1 < nt; t += 2) {       // two iterations per trip: the score registers swap roles (sA <-> sB) without copies
+        half1(t, sB, sA, T_{}, T_{});
+        sync(t);
+        half2(t, sB, T_{}, T_{}, F_{});
+        half1(t + 1, sA, sB, T_{}, T_{});
+        sync(t + 1);
+        if (t + 2 == nt && tail_masked) half2(t + 1, sA, T_{}, T_{}, T_{}); else half2(t + 1, sA, T_{}, T_{}, F_{});
+    }
+    if (t < nt) {                      // odd tile left: it is the last one
+        half1(t, sB, sA, T_{}, T_{});
+        sync(t);
+        if (tail_masked) half2(t, sB, T_{}, T_{}, T_{}); else half2(t, sB, T_{}, T_{}, F_{});
+        // drain: exp2 / pack and PV of the last tile (scores in sB)
+        half1(t + 1, sA, sB, F_{}, T_{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        half2(t + 1, sA, F_{}, T_{}, F_{});
+    } else {                           // the last tile's scores are in sA
+        half1(nt, sB, sA, F_{}, T_{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        half2(nt, sB, F_{}, T_{}, F_{});
     }
 
     if (prof_on) pt2 = prof_now();
-    // ---- epilogue: O[q][h*64 + df*16 + fg*4 + r] = o / l
     bf16_t* Ob = p.O + (int64_t)b * p.strideO + h * 64;
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const int q = q0 + qi * 16 + fr;
         if (q >= p.Sq) continue;
-        const float inv = 1.0f / lacc[qi][0];        // every row of the ones-MFMA result holds the full key sum
+        const float inv = 1.0f / lacc[qi][0];
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             uint2 v;
@@ -427,8 +464,7 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     if (!aligned16(Q) || !aligned16(K) || !aligned16(Vt) || (((uintptr_t)O) & 7)) TMIX_FAIL(TMIX_EALIGN, "attn: pointer alignment");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_P);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -448,16 +484,9 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
         TMIX_LAUNCH_CHECK();
         return TMIX_OK;
     }
-    // the 8-wave form (256-row workgroups) measured SLOWER in situ (S = 1024: 48.2 vs 37.8 us, S = 4096: 267 vs 221): one barrier
-    // over eight waves per tile costs more than the halved LDS-DMA issue saves, and two independent 4-wave workgroups per CU drift
-    // apart so that one's softmax overlaps the other's MFMAs.  Kept for experiments: TMIX_ATTN_WAVES=8.
-    const char* fw = getenv("TMIX_ATTN_WAVES");
-    const bool eight = fw && atoi(fw) == 8;
-    if (eight) p.nq = (Sq + 255) / 256;
     const int64_t nwg = (int64_t)p.nq * B * H;
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
-    if (eight) attn_fwd_kernel<8><<<dim3((unsigned)nwg), 512, SMEM, (hipStream_t)stream>>>(p);
-    else       attn_fwd_kernel<4><<<dim3((unsigned)nwg), 256, SMEM, (hipStream_t)stream>>>(p);
+    attn_fwd_pipe_kernel<<<dim3((unsigned)nwg), 256, SMEM_P, (hipStream_t)stream>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
