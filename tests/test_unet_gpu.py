@@ -116,6 +116,35 @@ def test_lora_merged_rows():
     torch.testing.assert_close(rows[0, :Cc], sd[f"{a1}.to_q.weight"], rtol=2 ** -7, atol=1e-3)
 
 
+def test_small_lora_delta_survives_the_merge_into_bf16_weights():
+    """the routed LoRA projections run on merged weights bf16(W + up @ down) (UNetWeights.merged) where the reference adds
+    up(down(x)) as a separate fp16 path (utils_lora.py:68,76-77,118; model_lora.py:41-48).  A delta near the bf16 ulp of W is NOT
+    rounded away: rounding W + delta leaves W + delta + e with the same e a bf16 copy of W alone carries, so over K = 1280 terms
+    the delta adds coherently and e as noise.  Measured here at deltas 100x smaller than the synthetic checkpoints' (|delta| ~ 1e-4,
+    the ulp of |W| ~ 0.03): (a) the delta's contribution recovered from the merged GEMM (merged minus base output) against the exact
+    x down^T up^T, and (b) the merged output's error against the exact fp32 result, which must not exceed the error the bf16 base
+    weights already have.  (The rank-4 epilogue form was priced and rejected: DESIGN.md section 4.2.)"""
+    from tweediemix_amd import ops
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 1024, 1280, 1280
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W32 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    down = (torch.randn(4, K, generator=g) * 0.25).cuda()
+    up = (torch.randn(N, 4, generator=g) * 0.02 * 0.01).cuda()          # 100x smaller than weights.synthetic_concepts
+    delta = up @ down
+    assert delta.abs().mean() < 2 * W32.abs().mean() * 2.0 ** -8           # at / below the bf16 ulp of W
+    y_exact = x.float() @ W32.T + (x.float() @ down.T) @ up.T
+    y_delta = (x.float() @ down.T) @ up.T
+    y_base = ops.gemm(x, W32.to(torch.bfloat16)).float()
+    y_merged = ops.gemm(x, (W32 + delta).to(torch.bfloat16)).float()
+    torch.cuda.synchronize()
+    rec = ((y_merged - y_base) - y_delta).norm() / y_delta.norm()
+    err_merged = (y_merged - y_exact).norm() / y_exact.norm()
+    err_base = (y_base - x.float() @ W32.T).norm() / y_exact.norm()
+    print(f"delta contribution recovered to rel. error {rec:.3f}; output error merged {err_merged:.2e} vs base-weights-only {err_base:.2e}")
+    assert rec < 0.5 and err_merged < 1.25 * err_base + 1e-4, (float(rec), float(err_merged), float(err_base))
+
+
 @pytest.mark.parametrize("force_tile", [1, 0])
 def test_plan_group_row_split_matches_single_plan(monkeypatch, force_tile):
     """PlanGroup (rows split over HIP streams) must give the rows a single plan gives: bit for bit when both use the same

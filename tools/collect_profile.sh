@@ -5,11 +5,11 @@
 tag=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-BARGS="--kind lora --no-trajectory --no-cpu-baseline ${BENCH_EXTRA:-}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag} -- python bench.py $BARGS > $out/bench.log 2>&1
-grep '^{"metric' $out/bench.log > $out/${tag}_bench_line.json
+BARGS="--kind lora --no-trajectory --no-cpu-baseline --no-video ${BENCH_EXTRA:-}"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag} -- python bench.py $BARGS > $out/${tag}_bench_line.json 2> $out/bench.log
 for pm in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_$pm.log 2>&1
+  # (each counter pass under its own timeout: a pass that hangs costs its own evidence, not the others')
+  timeout 600 rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_$pm.log 2>&1
 done
 python - $out $tag <<'PY'
 import csv, sys, json, collections, re
@@ -34,7 +34,7 @@ for k in res["FETCH_SIZE"]:
 json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(summary))
 PY
-rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_MFMA.log 2>&1
+timeout 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_MFMA.log 2>&1
 python - $out $tag <<'PY'
 import csv, sys, json, collections, re
 out, tag = sys.argv[1], sys.argv[2]
@@ -57,10 +57,20 @@ wavg = lambda v: sum(u * d for u, d in v) / sum(d for _u, d in v)
 res = {"per_kernel_class_time_weighted_percent": {k: wavg(v) for k, v in cls.items()},
        "per_instance": {k: {"launches": len(v), "time_weighted_percent": wavg(v), "max_percent": max(u for u, _d in v),
                             "total_ms": sum(d for _u, d in v) / 1e6} for k, v in sorted(agg.items())},
-       "note": "rocprofv3 --pmc MfmaUtil (SQ_VALU_MFMA_BUSY_CYCLES summed / (GRBM_GUI_ACTIVE x SIMDs)), eager single-stream pass of bench.py "
-               "(half-batch launches run alone, serialised by the profiler); averages weighted by kernel duration"}
+       "note": "rocprofv3 --pmc MfmaUtil (SQ_VALU_MFMA_BUSY_CYCLES summed / (GRBM_GUI_ACTIVE x SIMDs)); eager pass of bench.py (--no-graphs, "
+               "one launch chain at the full batch B = 4, the launches serialised by the profiler); averages weighted by kernel duration"}
 json.dump(res, open(f"{out}/{tag}_mfma_util.json", "w"), indent=1)
 print(json.dumps(res["per_kernel_class_time_weighted_percent"]))
 PY
 rm -f $out/*_kernel_trace.csv $out/*counter_collection.csv $out/*agent_info.csv
+# the manifest bench.py reads (copy it with the files into profiles/)
+python - $out $tag <<'PY'
+import json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+man = {"round_tag": tag, "kernel_stats": f"{tag}_kernel_stats.csv", "bench_line": f"{tag}_bench_line.json"}
+for key, f in (("traffic", f"{tag}_traffic.json"), ("mfma_util", f"{tag}_mfma_util.json")):
+    if os.path.exists(os.path.join(out, f)): man[key] = f
+json.dump(man, open(os.path.join(out, "MANIFEST.json"), "w"), indent=1)
+print(man)
+PY
 ls $out

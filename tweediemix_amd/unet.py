@@ -802,8 +802,9 @@ class UNetPlan:
         return self.eps
 
 
-def refine_group(self, top=14, reps=9, verbose=False):
-    """second tuning pass for the chains of a group: UNetPlan.autotune ranks tilings with one chain running alone, but a
+def refine_group(self, top=14, reps=9, verbose=False, cands=None):
+    """second tuning pass, for the chains of a group or for ONE plan (the event-timed eager ranking of UNetPlan.autotune is noisy
+    at the +-1 % level, and a captured graph schedules launches differently from eager issue): UNetPlan.autotune ranks tilings with one chain running alone, but a
     tiling that owns its CU (one workgroup, deep ring) can lose once the other chain competes for the same CUs.  For the
     `top` heaviest launch shapes every candidate is tried in place and the WHOLE group is timed as a captured graph
     (median of `reps` replays); the winner replaces the cache entry.  Used offline by tools/make_tune_table.py."""
@@ -825,8 +826,9 @@ def refine_group(self, top=14, reps=9, verbose=False):
             ts.append(e0.elapsed_time(e1))
         return sorted(ts)[len(ts) // 2]
 
+    plans = _plans_of(self)
     weight, members = {}, {}
-    for p in self.plans:
+    for p in plans:
         for _i, kind, d in p._tunable:
             k = p._tune_key(kind, d)
             fl = 2.0 * d.M * d.N * d.K * d.batch if kind == "gemm" else 2.0 * d.B * d.H * d.W * d.Cout * 9 * d.Cin
@@ -836,19 +838,19 @@ def refine_group(self, top=14, reps=9, verbose=False):
     for k in sorted(weight, key=weight.get, reverse=True)[:top]:
         cur = members[k][0][2].tile_cfg
         best, best_t = cur, base
-        for cfg in L.TILE_CANDIDATES:
-            if cfg == cur:
+        for cfg in (cands or L.TILE_CANDIDATES):
+            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 19, 20)):
                 continue
             for p, _kind, d in members[k]:
                 d.tile_cfg = cfg
-            for p in self.plans:
+            for p in plans:
                 p._link_ln()
             t = timed()
             if t < best_t - 0.02:                       # 20 us: above the replay-to-replay noise of the median
                 best, best_t = cfg, t
         for p, _kind, d in members[k]:
             d.tile_cfg = best
-        for p in self.plans:
+        for p in plans:
             p._link_ln()
         if verbose:
             print(f"  refine {k}: {cur} -> {best}  ({base:.3f} -> {best_t:.3f} ms)", flush=True)
@@ -899,6 +901,9 @@ def tilings_follow_table(plan):
             if want != d.tile_cfg:
                 bad.append((k, d.tile_cfg, want))
     return not bad, bad
+
+
+UNetPlan.refine = lambda self, **kw: refine_group(self, **kw)
 
 
 class PlanGroup:
