@@ -116,33 +116,37 @@ def test_lora_merged_rows():
     torch.testing.assert_close(rows[0, :Cc], sd[f"{a1}.to_q.weight"], rtol=2 ** -7, atol=1e-3)
 
 
-def test_small_lora_delta_survives_the_merge_into_bf16_weights():
+@pytest.mark.parametrize("scale", [1.0, 0.01])
+def test_lora_delta_merged_into_bf16_weights(scale):
     """the routed LoRA projections run on merged weights bf16(W + up @ down) (UNetWeights.merged) where the reference adds
-    up(down(x)) as a separate fp16 path (utils_lora.py:68,76-77,118; model_lora.py:41-48).  A delta near the bf16 ulp of W is NOT
-    rounded away: rounding W + delta leaves W + delta + e with the same e a bf16 copy of W alone carries, so over K = 1280 terms
-    the delta adds coherently and e as noise.  Measured here at deltas 100x smaller than the synthetic checkpoints' (|delta| ~ 1e-4,
-    the ulp of |W| ~ 0.03): (a) the delta's contribution recovered from the merged GEMM (merged minus base output) against the exact
-    x down^T up^T, and (b) the merged output's error against the exact fp32 result, which must not exceed the error the bf16 base
-    weights already have.  (The rank-4 epilogue form was priced and rejected: DESIGN.md section 4.2.)"""
+    up(down(x)) as a separate fp16 path (utils_lora.py:68,76-77,118; model_lora.py:41-48).  What that costs, measured on one
+    1280-wide projection: (a) the OUTPUT error against the exact fp32 x W^T + x down^T up^T must not exceed the error a bf16 copy
+    of W alone already has (rounding W + delta leaves the same e as rounding W) -- asserted at the synthetic checkpoints' delta size
+    and at deltas 100x smaller (|delta| ~ 1e-4, the ulp of |W| ~ 0.03); (b) the delta's own contribution, recovered as merged
+    minus base output: exact to ~1 % at the checkpoints' size, but only dithered at the 100x smaller size (printed: ~0.9 relative
+    error, i.e. below the bf16-weight noise floor that ANY bf16-W form of this GEMM has, the rank-4 epilogue form included; that
+    form would resolve the delta itself exactly).  DESIGN.md section 4.2 prices the epilogue form."""
     from tweediemix_amd import ops
     g = torch.Generator().manual_seed(21)
     M, N, K = 1024, 1280, 1280
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     W32 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
     down = (torch.randn(4, K, generator=g) * 0.25).cuda()
-    up = (torch.randn(N, 4, generator=g) * 0.02 * 0.01).cuda()          # 100x smaller than weights.synthetic_concepts
+    up = (torch.randn(N, 4, generator=g) * 0.02 * scale).cuda()            # scale 1 = weights.synthetic_concepts
     delta = up @ down
-    assert delta.abs().mean() < 2 * W32.abs().mean() * 2.0 ** -8           # at / below the bf16 ulp of W
-    y_exact = x.float() @ W32.T + (x.float() @ down.T) @ up.T
     y_delta = (x.float() @ down.T) @ up.T
+    y_exact = x.float() @ W32.T + y_delta
     y_base = ops.gemm(x, W32.to(torch.bfloat16)).float()
     y_merged = ops.gemm(x, (W32 + delta).to(torch.bfloat16)).float()
     torch.cuda.synchronize()
-    rec = ((y_merged - y_base) - y_delta).norm() / y_delta.norm()
-    err_merged = (y_merged - y_exact).norm() / y_exact.norm()
-    err_base = (y_base - x.float() @ W32.T).norm() / y_exact.norm()
-    print(f"delta contribution recovered to rel. error {rec:.3f}; output error merged {err_merged:.2e} vs base-weights-only {err_base:.2e}")
-    assert rec < 0.5 and err_merged < 1.25 * err_base + 1e-4, (float(rec), float(err_merged), float(err_base))
+    rec = float(((y_merged - y_base) - y_delta).norm() / y_delta.norm())
+    err_merged = float((y_merged - y_exact).norm() / y_exact.norm())
+    err_base = float((y_base - x.float() @ W32.T).norm() / y_exact.norm())
+    print(f"|delta|/ulp(W) = {float(delta.abs().mean() / (W32.abs().mean() * 2.0 ** -8)):.2f}: delta contribution recovered to rel. error "
+          f"{rec:.3f}; output error merged {err_merged:.2e} vs base-weights-only {err_base:.2e}")
+    assert err_merged < 1.25 * err_base + 1e-4, (err_merged, err_base)
+    if scale == 1.0:
+        assert rec < 0.05, rec
 
 
 @pytest.mark.parametrize("force_tile", [1, 0])
