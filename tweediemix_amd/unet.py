@@ -416,14 +416,12 @@ class UNetPlan:
             idx = {i: n for n, (i, _k, _d) in enumerate(tun)}
             st = torch.cuda.current_stream().cuda_stream
             best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
-            # the loader-wave tilings (8..11) win isolated launches by 7-27 % and in-sequence eager launches by 2-4 %, but a
-            # 9-wave / 147 KB workgroup owns its CU: in graph replay the next kernel (or the other chain) cannot move in
-            # while it drains, and whole steps came out 0-3 % SLOWER -- so they are candidates only on request
-            cands = list(L.TILE_CANDIDATES) + (list(L.TILE_LW) if os.environ.get("TMIX_TUNE_LW") else [])
+            cands = list(L.TILE_CANDIDATES)                         # (16 / 17 and the loader-wave tilings 19 / 20 exist for the plain GEMM only)
+            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 20: 12}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
             for _rep in range(reps):
                 for cfg in cands:
                     for _i, kind, d in tun:
-                        d.tile_cfg = cfg if (kind == "gemm" or cfg not in L.TILE_LW) else 1
+                        d.tile_cfg = cfg if kind == "gemm" else conv_alias.get(cfg, cfg)
                     self._link_ln()
                     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in tun]
                     for i, (fn, args) in enumerate(self.ops):
@@ -442,7 +440,7 @@ class UNetPlan:
                     for k, t in tot.items():
                         best_t[(k, cfg)] = min(best_t.get((k, cfg), float("inf")), t)
             for k in set(keys):
-                ok = [c for c in cands if k.startswith("('gemm'") or c not in L.TILE_LW]
+                ok = [c for c in cands if k.startswith("('gemm'") or c not in conv_alias]
                 if k not in _TUNE_CACHE:
                     _TUNE_CACHE[k] = min(ok, key=lambda c: best_t[(k, c)])
                 if SHARED + k not in _TUNE_CACHE:     # starting point for chains that share the chip (refine_group re-ranks under load)
