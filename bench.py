@@ -362,8 +362,8 @@ def run_trajectories(tw, args, rank, world, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_backend() != "gloo":
-        dt = D.max_over_ranks(dt, device)
+    if dist.is_initialized():
+        dt = D.max_over_ranks(dt, torch.device("cpu") if dist.get_backend() == "gloo" else device)
     del co
     torch.cuda.empty_cache()
     out.update({"images": total, "seconds": dt, "images_per_s": total / dt if dt > 0 else 0.0, "cobatch": C_,
