@@ -148,6 +148,13 @@ typedef struct {
     int32_t ln_parts, reserved0;                      /* partials per row in ln_stats, 1..16 */
 } tmix_gemm_desc;
 int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
+/* Hint for the NEXT tmix_gemm_bf16 / tmix_conv3x3_nhwc launch issued by this host thread (consumed and cleared by it): while its
+ * workgroups wait for their own first operands they touch [next_weights, next_weights + bytes) -- one 4-byte load per 128-byte line, the
+ * range split evenly over the grid -- so that the weights of the launch that FOLLOWS it are in the memory-side (Infinity) cache when that
+ * launch starts (a dependent chain of launches otherwise meets every weight cold from HBM: fusion_sampling.py:340 calls the UNet's
+ * ~490 Linear / Conv2d layers back to back).  Purely a performance hint: no effect on results; bytes <= 0 or NULL clears it.
+ * `stream` is ignored (present so that the call has the shape of every other launch entry). */
+int tmix_gemm_prefetch_next(const void* next_weights, int64_t bytes, void* stream);
 /* The same GEMM on OCP fp8 (e4m3) operands -- the reference's precision bar is fp16 autocast (fusion_sampling.py:492); this is
  * the optional lower-precision path for the FF / QKV projections (`--dtype fp8`), never the default.  A and W hold e4m3 BYTES
  * (lda / ldw / strides in elements = bytes, multiples of 16; K %% 64 == 0) and every A row and W row carries one power-of-two

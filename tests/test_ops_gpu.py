@@ -722,3 +722,24 @@ def test_gemm_fp8_geglu_output_as_mx_blocks_feeds_the_next_gemm(ops, tile):
     w28, sw2 = ops.quantize_fp8_rows(w2)
     out = ops.gemm_fp8(c8, cs, w28, sw2, tile_cfg=tile, a_block_scales=True)
     close(out, deq @ ops.dequantize_fp8_rows(w28, sw2).t())
+
+
+@pytest.mark.parametrize("cfg", [7, 12, 16, 18, 20])
+def test_prefetch_hint_changes_nothing_but_timing(ops, cfg):
+    """tmix_gemm_prefetch_next: the launch that consumes the hint touches another tensor while it waits for its own operands --
+    its C is bit-identical to the un-hinted launch, the hinted range is only read, and the hint is consumed by ONE launch."""
+    import ctypes as C
+    from tweediemix_amd import lib as L
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    a, w = rnd(520, 256, seed=3), rnd(640, 256, seed=4, scale=256 ** -0.5)
+    nxt = rnd(3000, 1280, seed=5)                      # 7.7 MB of "next weights" (not a multiple of the grid's share)
+    keep = nxt.clone()
+    ref = ops.gemm(a, w, tile_cfg=cfg).clone()
+    L.check(lib.tmix_gemm_prefetch_next(nxt.data_ptr(), nxt.numel() * 2, st))
+    got = ops.gemm(a, w, tile_cfg=cfg).clone()
+    again = ops.gemm(a, w, tile_cfg=cfg)                # no hint pending any more
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and torch.equal(again, ref) and torch.equal(nxt, keep)
+    assert lib.tmix_gemm_prefetch_next(nxt.data_ptr(), 1 << 40, st) < 0          # larger than 2 GiB: refused
+    L.check(lib.tmix_gemm_prefetch_next(None, 0, st))                            # clears

@@ -25,6 +25,19 @@ extern "C" int tmix_prof_end(void) {
     return used;
 }
 
+static thread_local const char* g_pf_ptr = nullptr;
+static thread_local long long g_pf_bytes = 0;
+void tmix_prefetch_take(const char** ptr, long long* bytes) {
+    *ptr = g_pf_bytes > 0 ? g_pf_ptr : nullptr; *bytes = g_pf_bytes > 0 ? g_pf_bytes : 0;
+    g_pf_ptr = nullptr; g_pf_bytes = 0;
+}
+extern "C" int tmix_gemm_prefetch_next(const void* next_weights, int64_t bytes, void* /*stream*/) {
+    if (bytes > (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm_prefetch_next: %lld bytes (at most 2 GiB)", (long long)bytes);
+    g_pf_ptr = (next_weights && bytes > 0) ? (const char*)next_weights : nullptr;
+    g_pf_bytes = g_pf_ptr ? bytes : 0;
+    return TMIX_OK;
+}
+
 extern "C" int tmix_version(void) { return TMIX_VERSION; }
 extern "C" const char* tmix_last_error_string(void) { return g_err; }
 

@@ -75,6 +75,8 @@ static inline unsigned long long* tmix_prof_take(int* detail = nullptr) {
     if (!st.buf || st.next >= st.cap) return nullptr;
     return st.buf + 8 * (size_t)(st.next++);
 }
+// tmix_gemm_prefetch_next: the hint for the next GEMM / conv launch of this thread (capi.cpp); taking it clears it
+void tmix_prefetch_take(const char** ptr, long long* bytes);
 __device__ __forceinline__ unsigned long long prof_now() { return __builtin_amdgcn_s_memrealtime(); }
 // call from ONE thread per workgroup; `first` = this is the workgroup dispatched first (linear block id 0)
 __device__ __forceinline__ unsigned long long prof_enter(unsigned long long* slot, bool first, int detail) {

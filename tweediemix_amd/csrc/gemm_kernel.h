@@ -63,6 +63,7 @@ struct Params {
     int64_t ldScaleA;                 // fp8 with MX block scales on A (PH = 3): scaleA is [K/32][ldScaleA] (k-block major)
     unsigned char* scale_out; int64_t ldScaleOut; int f8out;    // GEGLU output as e4m3 bytes + [N/64][ldScaleOut] block scales
     unsigned char* f8copy; int64_t ldF8copy;                    // plain epilogue: e4m3 COPY of the stored bf16 rows (+ scale_out [N/32][ldScaleOut])
+    const char* pf; long long pf_bytes;                         // tmix_gemm_prefetch_next: the next launch's weights, touched in the prologue
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -134,6 +135,24 @@ gemm_conv_kernel(const Params p) {
     const bool prof_on = p.prof != nullptr && tid == 0;
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
     if (prof_on) pt0 = prof_enter(p.prof, (blockIdx.x | blockIdx.y) == 0, p.prof_detail);
+    // ---- the NEXT launch's weights (tmix_gemm_prefetch_next): this workgroup's share, one dword per 128-byte line, requested
+    // before the first operands of its own tile -- the prologue waits one memory round trip for those anyway, and these loads are
+    // older in the queue, so the counted vmcnt waits below cover them.  The destinations stay reserved (pf_keep) until then.
+    constexpr int PFU = 8;
+    unsigned pf_keep[PFU];
+#pragma unroll
+    for (int u = 0; u < PFU; ++u) pf_keep[u] = 0;
+    // (with loader waves only they touch: the math waves never wait on vmcnt, so nothing would cover their loads)
+    if (p.pf && (!LW || w >= WM * WN)) {
+        const long long nwg = (long long)gridDim.x * gridDim.y, nth = (LW ? LW : WM * WN * KS) * 64;
+        const long long lines = (p.pf_bytes + 127) >> 7, per = (lines + nwg * nth - 1) / (nwg * nth);     // lines per thread
+        const long long first = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * nth + (LW ? tid - WM * WN * 64 : tid);
+#pragma unroll
+        for (int u = 0; u < PFU; ++u) {
+            const long long ln = first + (long long)u * nwg * nth;
+            if (u < per && ln < lines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_keep[u]) : "v"(p.pf + (ln << 7)) : "memory");
+        }
+    }
     const bool loader = LW && (w >= NW);               // wave-uniform role
     const bool stager = LW ? loader : true;
     const int sw_id = LW ? max(w - NW, 0) : w;         // this wave's slot among the staging waves
@@ -293,6 +312,8 @@ gemm_conv_kernel(const Params p) {
             for (int s = 0; s < NS - 1; ++s)
                 if (s < nk) stage(s, s);
             if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+#pragma unroll
+            for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));
             __builtin_amdgcn_s_barrier();
             int nxt = NS - 1;
             for (int kt = 0; kt < nk; ++kt) {
@@ -468,6 +489,8 @@ gemm_conv_kernel(const Params p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (prof_on) pt1 = prof_now();
+#pragma unroll
+        for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));        // the prefetch touches have returned (older than the tiles waited for)
         if (grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
         // One slice: LOAD segment (fragment reads of slice s; the wait that makes slice s + 1 visible), barrier, MFMA
         // segment, barrier.  The LDS-DMA instructions of slice s + 3 are issued INSIDE the MFMA cluster, one after every
@@ -576,6 +599,8 @@ gemm_conv_kernel(const Params p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (prof_on) pt1 = prof_now();
+#pragma unroll
+    for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));            // the prefetch touches have returned (older than the tiles waited for)
     int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
     constexpr int KPW = 4 / KS;                        // k-steps of this wave's split-K group
     const int k0 = kg * KPW;
@@ -1224,6 +1249,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     if (BM >= 256 && BN >= 256) p.group_m = 8;
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     p.prof = tmix_prof_take(&p.prof_detail);
+    tmix_prefetch_take(&p.pf, &p.pf_bytes);
     kern<<<grid, (WM * WN * KS + LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;

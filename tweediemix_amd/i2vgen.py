@@ -12,6 +12,7 @@ size of the published fp16 checkpoint.  Tests compare this plan with oracle/i2vg
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -223,6 +224,7 @@ class I2VPlan(UNetPlan):
         self.op_meta = {}
         self.fp8 = False                                 # (the fp8 projections are wired for the image UNet only)
         self._tunable, self._ln_links, self._vt = [], [], {}
+        self._pf_prev, self._pf_on = None, not os.environ.get("TMIX_NO_PREFETCH")      # next-launch weight prefetch hints (UNetPlan._hint_weights)
         self.kv = _KV(W, context, frames)
         self.x_in = torch.zeros(B, 2 * cfg.in_channels, h, w, device=dev, dtype=F32)
         self.x_in.view(clips, frames, 2 * cfg.in_channels, h, w)[:, :, cfg.in_channels:] = il_feat.to(dev, F32).permute(0, 2, 1, 3, 4)

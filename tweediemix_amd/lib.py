@@ -66,6 +66,7 @@ SIGNATURES = {
                                               C.c_int, vp, vp]),
     "tmix_step_prologue": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, i64, vp]),
     "tmix_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "tmix_gemm_prefetch_next": (C.c_int, [vp, i64, vp]),
     "tmix_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp, vp, vp]),
     "tmix_quantize_fp8_rows": (C.c_int, [vp, i64, vp, i64, vp, i64, C.c_int, vp]),
     "tmix_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), vp]),

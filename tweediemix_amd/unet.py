@@ -380,6 +380,10 @@ class UNetPlan:
             lvl = nb - 1 if pfx.startswith("mid") else int(pfx.split(".")[1]) if pfx.startswith("down") else nb - 1 - int(pfx.split(".")[1])
             need = max(need, ((cc + 127) // 128) * B * (h >> lvl) * (w >> lvl) * 2)
         self._ln_buf = torch.zeros(need, device=dev, dtype=F32)
+        # every GEMM / conv launch is preceded by a tmix_gemm_prefetch_next hint naming the weights of the launch AFTER it (patched in
+        # when that launch is planned): the chain otherwise meets every weight cold from HBM (TMIX_NO_PREFETCH=1 switches it off)
+        self._pf_prev = None
+        self._pf_on = not os.environ.get("TMIX_NO_PREFETCH")
         self._tunable = []                  # (index into self.ops, kind, descriptor) of every GEMM / conv launch
         self._ln_links = []                 # (producer desc, [consumer descs]): ln_parts follows the producer's tiling
         self._build()
@@ -454,6 +458,17 @@ class UNetPlan:
     def _emit(self, fn, *args):
         self.ops.append((fn, args))
 
+    def _hint_weights(self, w):
+        """called when a GEMM / conv launch over weight tensor `w` is planned, BEFORE its op is emitted: names `w` in the previous
+        launch's prefetch hint and opens this launch's own hint slot."""
+        if not self._pf_on:
+            return
+        if self._pf_prev is not None:
+            self._pf_prev[0], self._pf_prev[1] = w.data_ptr(), w.numel() * w.element_size()
+        self._pf_prev = [None, 0]
+        self.keep.append(w)
+        self.ops.append((self.lib.tmix_gemm_prefetch_next, self._pf_prev))
+
     def _gn(self, x, Cc, HW, name, eps, silu, out=None):
         out = out if out is not None else self.arena.get(self.B, HW, Cc)
         W = self.W
@@ -480,6 +495,7 @@ class UNetPlan:
         elif kw.get("ln_stats") is not None:
             self._ln_links[-1][1].append(d)
         self.keep.append(d)
+        self._hint_weights(w)
         self._emit(self.lib.tmix_gemm_bf16, C.byref(d))
         fl = 2 * d.M * d.N * d.K * d.batch
         self.flops += fl
@@ -527,6 +543,7 @@ class UNetPlan:
         elif kw.get("ln_stats") is not None:
             self._ln_links[-1][1].append(d)
         self.keep += [d, a8, sa]
+        self._hint_weights(w8)
         self._emit(self.lib.tmix_gemm_fp8, C.byref(d), sa.data_ptr(), sw.data_ptr())
         fl = 2 * d.M * d.N * d.K * d.batch
         self.flops += fl
@@ -543,6 +560,7 @@ class UNetPlan:
         d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Cin), self.W[wname + ".weight"], out.view(self.B, Ho, Wo, Cout),
                                self.W[wname + ".bias"], batch_bias, residual, mode, bias_images=bias_images)
         self.keep.append(d)
+        self._hint_weights(self.W[wname + ".weight"])
         self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
         fl = 2 * self.B * Ho * Wo * Cout * 9 * Cin
         self.flops += fl
