@@ -118,7 +118,8 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_128x160_S4_K2 = 18 /* tiling 12 with in-workgroup split-K: two groups of four waves share the tile (eight waves stage) */,
        TMIX_TILE_128x160_S3_LW = 19 /* 128x160, 3-deep ring, plus ONE loader wave: the four math waves issue no VMEM instruction in the K loop */,
        TMIX_TILE_128x160_S4_LW2 = 20 /* tiling 12 plus TWO loader waves (each issues every other LDS-DMA instruction of a K-tile) */,
-       TMIX_TILE_COUNT = 20 };
+       TMIX_TILE_128x160_S4_LW4 = 21 /* tiling 12 plus FOUR loader waves: one per SIMD, nine LDS-DMA instructions of a K-tile each */,
+       TMIX_TILE_COUNT = 21 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

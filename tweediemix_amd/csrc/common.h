@@ -13,15 +13,23 @@ typedef __attribute__((ext_vector_type(4))) float  f32x4;    // 16x16 accumulato
 typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator fragment
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, on gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer form -- NaN test, rounding
+// add, shift, merge -- was ~14 VALU per pair, and with one wave per SIMD the GEMM epilogues are VALU-issue bound: tools/jobs/r3za_epi_abl.sh)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#if defined(TMIX_ABL_SW_BF16)   // dev A/B builds only (tools/build_variant.sh): the integer form this replaced
+    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a = ((a & 0x7fffffffu) > 0x7f800000u) ? ((a >> 16) | 0x40u) : ((a + 0x7fffu + ((a >> 16) & 1u)) >> 16);
+    b = ((b & 0x7fffffffu) > 0x7f800000u) ? ((b >> 16) | 0x40u) : ((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+    return (a & 0xffffu) | (b << 16);
+#else
+    const f32x2_hw f = {lo, hi};
+    const bf16x2_hw b = __builtin_convertvector(f, bf16x2_hw);
+    return __builtin_bit_cast(uint32_t, b);
+#endif
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (diffusers GEGLU uses F.gelu with approximate='none').  erf by Abramowitz-Stegun 7.1.26
 // (|err| <= 1.5e-7, far below the bf16 output rounding) on v_rcp_f32 / v_exp_f32: ~14 VALU instead of ~40 for

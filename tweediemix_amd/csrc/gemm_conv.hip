@@ -28,7 +28,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         }
     }
     if (p.f8copy) {                // the e4m3 copy of C is compiled into the tilings that have registers to spare for it (F8C)
-        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12};
+        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12};
         // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
         if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
         cfg = alt[cfg];
@@ -64,7 +64,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
                                               {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160},
-                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}};
+                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}, {128, 160}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

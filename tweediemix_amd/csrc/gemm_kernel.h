@@ -28,7 +28,8 @@ namespace tmix_gemm {
 
 // TMIX_ABL (dev builds under tools/ab/ only; the shipped library is built without it): ablations that locate the bound of a
 // launch -- bit 0: every workgroup stages tile (0, 0) (operands L2-hot, no fabric traffic), bit 1: no MFMAs (fragments are read
-// and kept alive), bit 2: no LDS-DMA inside the K loop (the prologue's tiles are re-read), bit 3: no epilogue stores.
+// and kept alive), bit 2: no LDS-DMA inside the K loop (the prologue's tiles are re-read), bit 3: no epilogue at all; staged plain epilogue only:
+// bit 4: no bias loads, bit 5: no C stores (everything else runs), bit 6: the residual is neither requested nor added.
 #ifndef TMIX_ABL
 #define TMIX_ABL 0
 #endif
@@ -191,7 +192,7 @@ gemm_conv_kernel(const Params p) {
         if (loader) {
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
-                const int par = (LW == 2) ? sw_id : pp;   // two loaders: instruction parity = loader id (both slots hold it)
+                const int par = (LW >= 2) ? (sw_id & 1) : pp;   // two / four loaders: instruction parity = loader id & 1 (both slots hold it)
                 const unsigned sw = ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 8;
                 swp[pp] = sw;
                 woffp[pp] = ((unsigned)(n0l + par * 8 + lrow) * (unsigned)p.ldw + sw) * 2u;
@@ -428,7 +429,7 @@ gemm_conv_kernel(const Params p) {
     constexpr int WP_I = (FN / 2) * 4 + (FN & 1) * 2;          // 16-byte residual pieces per lane per 32-row block
     constexpr bool WPREF = FM * WP_I <= 12;
     uint4 rw[WPREF ? FM * WP_I : 1];
-    const bool wide_res = WPREF && Rb && (p.wide & 1) && kg == 0;
+    const bool wide_res = WPREF && Rb && (p.wide & 1) && kg == 0 && !(ABL & 64);
     auto prefetch_residual_wide = [&]() {
         if constexpr (WPREF) {
             auto grab = [&](int j0, int base, auto cf_tag) {
@@ -1007,7 +1008,7 @@ gemm_conv_kernel(const Params p) {
             float bv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) bv[k] = 0.f;
-            if (bias && ncok) {
+            if (bias && ncok && !(ABL & 16)) {
                 const float4 b0 = *(const float4*)(bias + nc), b1 = *(const float4*)(bias + nc + 4);
                 bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
             }
@@ -1015,7 +1016,7 @@ gemm_conv_kernel(const Params p) {
             for (int i = 0; i < FM; ++i) {
                 const int mb = m0 + wr * TM + i * 32;
                 uint4 rv[NP];
-                if (Rb) {
+                if (Rb && !(ABL & 64)) {
 #pragma unroll
                     for (int ps = 0; ps < NP; ++ps) {
                         const int m = mb + ps * RPI + rr;
@@ -1053,7 +1054,7 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = o[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * o[k]));
                     }
-                    if (Rb) {
+                    if (Rb && !(ABL & 64)) {
                         const unsigned u[4] = {rv[ps].x, rv[ps].y, rv[ps].z, rv[ps].w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { o[2 * k] += bf2f((bf16_t)(u[k] & 0xffff)); o[2 * k + 1] += bf2f((bf16_t)(u[k] >> 16)); }
@@ -1065,7 +1066,8 @@ gemm_conv_kernel(const Params p) {
                     } else {
                         uint4 v;
                         v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
-                        *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
+                        if constexpr (ABL & 32) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                        else *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
                         if constexpr (F8C) if (p.f8copy) {
                             // the next GEMM's A operand: the row AS STORED, as e4m3 with one E8M0 scale per 32 columns (MX block = the 4
                             // adjacent lanes of this row; M % 32 == 0 and N % 32 == 0, so a block's lanes are all here)
@@ -1228,8 +1230,9 @@ struct TileCfg { int bm, bn; };
 // 16 = 256x256, 17 = 256x128 with the PHASE-OFFSET mainloop (PH: eight waves, K slices of 32 through a four-slot ring, the
 // second wave of every SIMD one barrier behind the first; GEMM only, no transposed region)
 // 18 = tiling 12 (128x160, 4-deep ring) with in-workgroup split-K over two wave groups (KS = 2): eight waves stage, GEMM only
-// 19 / 20 = tiling 12 (128x160, 4-deep ring) with one / two LOADER waves next to the four math waves (GEMM only)
-constexpr int NUM_CFG = 20;
+// 19 / 20 / 21 = tiling 12 (128x160, 4-deep ring) with one / two / FOUR LOADER waves next to the four math waves (GEMM only); with four
+// every SIMD hosts one math wave and one loader, and a K-tile's 36 LDS-DMA instructions are nine per loader
+constexpr int NUM_CFG = 21;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 int launch_cfg(Params& p, int batch, hipStream_t st) {

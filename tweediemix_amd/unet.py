@@ -421,7 +421,7 @@ class UNetPlan:
             st = torch.cuda.current_stream().cuda_stream
             best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
             cands = list(L.TILE_CANDIDATES)                         # (16 / 17 and the loader-wave tilings 19 / 20 exist for the plain GEMM only)
-            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 20: 12}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
+            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 20: 12, 21: 12}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
             for _rep in range(reps):
                 for cfg in cands:
                     for _i, kind, d in tun:
