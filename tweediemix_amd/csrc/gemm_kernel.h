@@ -337,6 +337,12 @@ gemm_conv_kernel(const Params p) {
     uint4* ln_mfrag = (uint4*)(smem + RING);          // [BM] -mean pieces, [BN] colsum pieces, then float rstd[BM]
     uint4* ln_cfrag = ln_mfrag + BM;
     float* ln_rs = (float*)(ln_cfrag + BN);
+    // the tile's BN bias values (zeros without a bias) for the straight-line staged epilogue: fetched here, parked in LDS by ln_reduce --
+    // a load issued between the epilogue's stores would queue behind them (vmcnt counts stores too), and 8 values per chunk kept in
+    // registers across the last K-tiles pushed the 128 x 160 tilings past 256 VGPRs
+    float* bias_lds = ln_rs + BM;
+    float bias_r = 0.f;
+    if (p.bias && tid < BN && n0 + tid < p.N) bias_r = (p.bias + (int64_t)bz * p.strideBias)[n0 + tid];
     constexpr int PU = 16;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     u32x2 lnv[PU];
@@ -357,6 +363,7 @@ gemm_conv_kernel(const Params p) {
     // x = x1 + x2 + x3 (bf16 pieces by truncation, exact residuals): operand halves {x1,x1,x2,0 | x1,x3,x2,0} for -mean
     // and {x1,x2,x1,0 | x3,x1,x2,0} for colsum pair up to the six products x_a * y_b with a + b <= 4 (~24 bits)
     auto ln_reduce = [&]() {
+        if (tid < BN) bias_lds[tid] = bias_r;
         if (!ln_on) return;
         if (tid < BM) {
             float s1 = 0.f, s2 = 0.f;
@@ -448,6 +455,17 @@ gemm_conv_kernel(const Params p) {
             if constexpr (FN & 1) grab(FN - 1, (FN / 2) * 4, std::integral_constant<int, 1>{});
         }
     };
+    // in front of the last K-tile's MFMAs.  A launch without residual gets zeros there instead (the straight-line epilogue adds them
+    // unconditionally); the registers become live here, not in front of the K loop.
+    auto epi_prefetch = [&]() __attribute__((always_inline)) {
+        if constexpr (WPREF) {
+            if (wide_res) prefetch_residual_wide();
+            else {
+#pragma unroll
+                for (int q = 0; q < FM * WP_I; ++q) rw[q] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
     // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
     if constexpr (PH) {
         constexpr int PL = PA + PB;                    // this wave's DMA instructions per slice
@@ -469,7 +487,7 @@ gemm_conv_kernel(const Params p) {
         // then reads byte [2 s + half][its row] in the LOAD segment of slice s.  (Streaming them through registers with
         // global_load_ubyte one slice ahead was tried first: the compiler copies loop-carried registers at the back edge, i.e.
         // while such a load is still in flight -- nothing it can see orders that copy behind the counted wait.)
-        char* const scl = smem + RING + (BM + BN) * 16 + BM * 4;
+        char* const scl = smem + RING + (BM + BN) * 16 + BM * 4 + BN * 4;          // behind the fused-LayerNorm block and the bias block
         if constexpr (F8B) {
             const int nblk = p.K / 32;
             const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)p.scaleA, 0, (int)((int64_t)nblk * p.ldScaleA), 0x00020000);
@@ -536,7 +554,7 @@ gemm_conv_kernel(const Params p) {
             }
             if (s + 2 < ns) wait_vmcnt<PL>(); else wait_vmcnt<0>();
             if (PREF && s == ns - 1 && Rb && plain_epi) prefetch_residual();     // rides under the last MFMA segment
-            if (s == ns - 1 && wide_res) prefetch_residual_wide();
+            if (s == ns - 1) epi_prefetch();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -659,7 +677,7 @@ gemm_conv_kernel(const Params p) {
         if constexpr (CONV && MORE) { stage(nxt, kt + NS - 1); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (!decltype(more_tag)::value) {   // residual rows of the epilogue: requested in front of the LAST K-tile
             if (PREF && kt == nk - 1 && Rb && plain_epi) prefetch_residual();
-            if (kt == nk - 1 && wide_res) prefetch_residual_wide();
+            if (kt == nk - 1) epi_prefetch();
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1000,11 +1018,64 @@ gemm_conv_kernel(const Params p) {
             for (int q = 0; q < 4; ++q) { sa1[i][q] = 0.f; sa2[i][q] = 0.f; }
             sb1[i][0] = sb1[i][1] = sb2[i][0] = sb2[i][1] = 0.f;
         }
-        auto chunk = [&](int j0, auto cf_tag) {                  // CF fragments = CF * 32 fp32 columns of every 32-row block
+        // FL > 0: the STRAIGHT-LINE form for the common case (bf16 output, no activation, no time-embedding rows, no e4m3 copy; FL = 2
+        // also keeps the row statistics).  With one wave per SIMD the epilogue is bound by VALU issue and by the latencies nobody hides
+        // (tools/jobs/r3za_epi_abl.sh: 5.3 of its 6.7 us on 128 x 160 tiles remain with bias loads, residual and stores all removed), and the
+        // generic form below has a dozen wave-uniform branches per pass, each a scheduling barrier and a fetch bubble.  Here bias and
+        // residual come from registers filled in front of the last K-tile (zeros when the launch has none: x * 1 + 0 and x + 0 leave
+        // every value as it was), a lane outside the tile is handled by predicating its store, and the passes of a chunk interleave.
+        auto chunk = [&](int j0, auto cf_tag, auto fl_tag) __attribute__((always_inline)) {     // CF fragments = CF * 32 fp32 columns of every 32-row block
             constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, SR = CW * 4 + 16, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
+            constexpr int FL = WPREF ? decltype(fl_tag)::value : 0;
             const int rr = lane / LPR, cc = (lane % LPR) * 8;
             const int nc = n0 + wc * TN + j0 * 32 + cc;
             const bool ncok = nc < p.N;
+            if constexpr (FL > 0) {
+                constexpr int CI = CF == 2 ? 0 : (FN / 2) * 4;          // residual pieces of this chunk inside rw (plus (j0 / 2) * 4 for pairs)
+                const bool lnf = p.ln_stats != nullptr;
+                const float4 bq0 = *(const float4*)(bias_lds + wc * TN + j0 * 32 + cc), bq1 = *(const float4*)(bias_lds + wc * TN + j0 * 32 + cc + 4);
+                const float bq[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int mb = m0 + wr * TM + i * 32;
+#pragma unroll
+                    for (int jj = 0; jj < CF; ++jj)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *(float4*)(stg + l31 * SR + (jj * 32 + g * 8 + lhi * 4) * 4) =
+                                make_float4(acc[i][j0 + jj][g * 4 + 0], acc[i][j0 + jj][g * 4 + 1], acc[i][j0 + jj][g * 4 + 2], acc[i][j0 + jj][g * 4 + 3]);
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const int r = ps * RPI + rr, m = mb + r;
+                        const float4 v0 = *(const float4*)(stg + r * SR + cc * 4), v1 = *(const float4*)(stg + r * SR + cc * 4 + 16);
+                        const float rsl = ln_rs[wr * TM + i * 32 + r];       // (valid LDS also without the fused LayerNorm; discarded then)
+                        const float rs = lnf ? rsl : 1.f;
+                        float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = fmaf(o[k], rs, bq[k]);
+                        const uint4 rq = rw[i * WP_I + CI + (CF == 2 ? (j0 / 2) * 4 : 0) + ps];
+                        const unsigned ru[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { o[2 * k] += __uint_as_float(ru[k] << 16); o[2 * k + 1] += __uint_as_float(ru[k] & 0xffff0000u); }
+                        uint4 v;
+                        v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
+                        const bool ok = m < p.M && ncok;
+                        if (ok) *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
+                        if constexpr (FL == 2) {                        // statistics of the values AS STORED (same order as the generic form)
+                            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+                                a1 += lo + hi; a2 = fmaf(lo, lo, a2); a2 = fmaf(hi, hi, a2);
+                            }
+                            if (!ok) { a1 = 0.f; a2 = 0.f; }
+                            if constexpr (CF == 2) { sa1[i][ps] += a1; sa2[i][ps] += a2; } else { sb1[i][ps] += a1; sb2[i][ps] += a2; }
+                        }
+                    }
+                }
+                return;
+            }
             float bv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) bv[k] = 0.f;
@@ -1100,9 +1171,16 @@ gemm_conv_kernel(const Params p) {
         };
         // chunks of two fragments (64 columns: 8 lanes x 16 bytes per row), a last single one when FN is odd
         constexpr int C2 = FN / 2;
+        auto chunks = [&](auto fl_tag) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{});
-        if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{});
+            for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{}, fl_tag);
+            if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{}, fl_tag);
+        };
+        bool fastp = WPREF && !f32out && p.epilogue == TMIX_EPI_NONE && !p.rgb && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
+        if constexpr (F8C) fastp = fastp && !p.f8copy;
+        if (fastp && !sto) chunks(std::integral_constant<int, 1>{});
+        else if (fastp) chunks(std::integral_constant<int, 2>{});
+        else chunks(std::integral_constant<int, 0>{});
         if (sto) {
             // a row's partials sit in the lanes that stored its columns: reduce over those lanes (fixed butterfly order), the
             // group's first lane owns the row; the 32-column chunk's owners then add to the same slot (same wave: LDS in order)
@@ -1237,7 +1315,7 @@ constexpr int NUM_CFG = 21;
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
-    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4      // staging ring + fused-LayerNorm block
+    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4      // staging ring + fused-LayerNorm block + the tile's bias
                        + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
