@@ -7,6 +7,8 @@ import os, sys, argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("src"); ap.add_argument("dst")
 ap.add_argument("--cobatch", type=int, default=0); ap.add_argument("--top", type=int, default=40); ap.add_argument("--reps", type=int, default=9)
+ap.add_argument("--cands", default="")       # e.g. 2,12,20,21: only these tilings are tried (default: every candidate)
+ap.add_argument("--kinds", default="lora,custom")
 a = ap.parse_args()
 os.environ["TMIX_TUNE_FILE"] = a.src
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,11 +17,12 @@ import bench
 from tweediemix_amd import unet as U
 dev = torch.device("cuda:0")
 for seeds in ([1] + ([a.cobatch] if a.cobatch else [])):
-    for kind in ("lora", "custom"):
+    for kind in a.kinds.split(","):
         args = argparse.Namespace(kind=kind, res=1024, tiny=False, no_graphs=True, streams=1, seeds_per_gpu=seeds, dtype="bf16")
         tw, _ = bench.build_sampler(args, kind, dev, seed=7)
         for name, top in (("fusion", a.top), ("plain", a.top // 2)):
-            ms = tw.plan(name).refine(top=top if seeds == 1 else top // 2, reps=a.reps if seeds == 1 else 5, verbose=True)
+            ms = tw.plan(name).refine(top=top if seeds == 1 else top // 2, reps=a.reps if seeds == 1 else 5, verbose=True,
+                                       cands=[int(c) for c in a.cands.split(',')] if a.cands else None)
             print(f"refined {kind} seeds={seeds} {name}: {ms:.3f} ms per UNet call", flush=True)
         del tw
         torch.cuda.empty_cache()

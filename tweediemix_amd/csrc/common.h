@@ -31,21 +31,24 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact-erf GELU (diffusers GEGLU uses F.gelu with approximate='none').  erf by Abramowitz-Stegun 7.1.26
-// (|err| <= 1.5e-7, far below the bf16 output rounding) on v_rcp_f32 / v_exp_f32: ~14 VALU instead of ~40 for
-// erff(), which made the GEGLU epilogue a quarter of the FF1 GEMM's time.
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    const float r = 1.0f - p * t * e;
-    return copysignf(r, x);
+// exact-erf GELU (diffusers GEGLU uses F.gelu with approximate='none'): gelu(x) = x * Phi(x).  Phi(-a) = exp2(P(a)) with P the degree-7
+// polynomial fit of log2 Phi(-a) on a in [0, 5.5] (Chebyshev nodes; tools/fit_gelu.py), Phi(x) = x < 0 ? Phi(-|x|) : 1 - Phi(-|x|):
+// ONE transcendental (v_exp_f32) and 7 fma.  |gelu error| <= 7e-7 absolute and <= 5e-6 RELATIVE (also deep in the negative tail, where
+// the Abramowitz-Stegun 7.1.26 erf used before -- a v_rcp_f32 plus a v_exp_f32, quarter-rate instructions both -- had 1.7e-3 relative);
+// the GEGLU epilogue of FF1 is VALU-bound and spent a third of its instructions here.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float a = fminf(fabsf(x), 5.5f);
+    float p = -1.921234625e-06f;
+    p = __builtin_fmaf(p, a, 6.328849712e-05f);
+    p = __builtin_fmaf(p, a, -9.434208502e-04f);
+    p = __builtin_fmaf(p, a, 8.556272268e-03f);
+    p = __builtin_fmaf(p, a, -5.405228293e-02f);
+    p = __builtin_fmaf(p, a, -4.583817849e-01f);
+    p = __builtin_fmaf(p, a, -1.151278331e+00f);
+    p = __builtin_fmaf(p, a, -9.999938561e-01f);
+    const float e = __builtin_amdgcn_exp2f(p);                 // Phi(-|x|)
+    return x * (x < 0.f ? e : 1.0f - e);                        // (0.5 + copysign(0.5 - e, x) would cancel in the tail)
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 // smallest E8M0 exponent e (value 2^e, stored as e + 127) with amax * 2^-e <= 448, the e4m3 maximum; 0 for an all-zero block
 __device__ __forceinline__ int e8m0_for_amax(float amax) {

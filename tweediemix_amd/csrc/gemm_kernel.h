@@ -65,6 +65,7 @@ struct Params {
     unsigned char* scale_out; int64_t ldScaleOut; int f8out;    // GEGLU output as e4m3 bytes + [N/64][ldScaleOut] block scales
     unsigned char* f8copy; int64_t ldF8copy;                    // plain epilogue: e4m3 COPY of the stored bf16 rows (+ scale_out [N/32][ldScaleOut])
     const char* pf; long long pf_bytes;                         // tmix_gemm_prefetch_next: the next launch's weights, touched in the prologue
+    int pf_per;                                                 // 128-byte lines per touching thread (host-computed: a 64-bit division in every wave's prologue otherwise)
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -146,7 +147,7 @@ gemm_conv_kernel(const Params p) {
     // (with loader waves only they touch: the math waves never wait on vmcnt, so nothing would cover their loads)
     if (p.pf && (!LW || w >= WM * WN)) {
         const long long nwg = (long long)gridDim.x * gridDim.y, nth = (LW ? LW : WM * WN * KS) * 64;
-        const long long lines = (p.pf_bytes + 127) >> 7, per = (lines + nwg * nth - 1) / (nwg * nth);     // lines per thread
+        const long long lines = (p.pf_bytes + 127) >> 7; const int per = p.pf_per;     // lines per thread
         const long long first = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * nth + (LW ? tid - WM * WN * 64 : tid);
 #pragma unroll
         for (int u = 0; u < PFU; ++u) {
@@ -309,13 +310,20 @@ gemm_conv_kernel(const Params p) {
     // ---- loader wave (LW): leaves here, before any math-wave state (accumulators, fragments) becomes live
     if constexpr (LW) {
         if (loader) {                                  // ---- loader wave: DMA issue + counted waits only
+            // tile 0 is handed over as soon as it has landed with ONE more tile requested behind it; the remaining prologue tiles are
+            // requested while the math waves already multiply (each LDS-DMA instruction costs this wave ~100 issue cycles: with all
+            // NS - 1 tiles in front of the first barrier the math waves waited for 9-18 instructions they did not need yet)
+            constexpr int PRE = NS >= 4 ? 2 : NS - 1;
 #pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
+            for (int s = 0; s < PRE; ++s)
                 if (s < nk) stage(s, s);
-            if (nk >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+            if (nk >= PRE) wait_vmcnt<(PRE - 1) * L>(); else wait_vmcnt<0>();
 #pragma unroll
             for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));
             __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int s = PRE; s < NS - 1; ++s)
+                if (s < nk) stage(s, s);
             int nxt = NS - 1;
             for (int kt = 0; kt < nk; ++kt) {
                 const bool more = kt + NS - 1 < nk;
@@ -914,19 +922,17 @@ gemm_conv_kernel(const Params p) {
                 const int rr = lane / LPR, cc = (lane % LPR) * 8;
 #pragma unroll
                 for (int jj = 0; jj < CF; ++jj) {
-                    const int j = j0 + jj, nb = n0 + wc * TN + j * 32;
+                    const int j = j0 + jj;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        const int nv = nb + g * 8 + lhi * 4;
                         float o[4];
-                        float4 ba = {0.f, 0.f, 0.f, 0.f}, bg = ba;      // one 16-byte load each (the bias is 16-byte aligned, nv % 4 == 0)
-                        if (bias && nb < p.N) { ba = *(const float4*)(bias + nv); bg = *(const float4*)(bias + nv + 16); }
+                        // the tile's bias sits in LDS (zeros without one; parked by ln_reduce): no global load between the chunks' stores,
+                        // no branch in the arithmetic
+                        const float4 ba = *(const float4*)(bias_lds + wc * TN + j * 32 + g * 8 + lhi * 4), bg = *(const float4*)(bias_lds + wc * TN + j * 32 + g * 8 + lhi * 4 + 16);
                         const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bgv[4] = {bg.x, bg.y, bg.z, bg.w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float a = acc[i][j][g * 4 + r], gt = acc[i][j][(g + 2) * 4 + r];
-                            if (bias && nb < p.N) { a = fmaf(a, rs_row[i], bav[r]); gt = fmaf(gt, rs_row[i], bgv[r]); }
-                            else { a *= rs_row[i]; gt *= rs_row[i]; }
+                            const float a = fmaf(acc[i][j][g * 4 + r], rs_row[i], bav[r]), gt = fmaf(acc[i][j][(g + 2) * 4 + r], rs_row[i], bgv[r]);
                             o[r] = a * gelu_erf_f(gt);
                         }
                         uint2 v; v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]);
@@ -1026,7 +1032,7 @@ gemm_conv_kernel(const Params p) {
         // every value as it was), a lane outside the tile is handled by predicating its store, and the passes of a chunk interleave.
         auto chunk = [&](int j0, auto cf_tag, auto fl_tag) __attribute__((always_inline)) {     // CF fragments = CF * 32 fp32 columns of every 32-row block
             constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, SR = CW * 4 + 16, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
-            constexpr int FL = WPREF ? decltype(fl_tag)::value : 0;
+            constexpr int FL = decltype(fl_tag)::value;              // (tilings without the residual registers: launches without residual only)
             const int rr = lane / LPR, cc = (lane % LPR) * 8;
             const int nc = n0 + wc * TN + j0 * 32 + cc;
             const bool ncok = nc < p.N;
@@ -1053,10 +1059,12 @@ gemm_conv_kernel(const Params p) {
                         float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = fmaf(o[k], rs, bq[k]);
-                        const uint4 rq = rw[i * WP_I + CI + (CF == 2 ? (j0 / 2) * 4 : 0) + ps];
-                        const unsigned ru[4] = {rq.x, rq.y, rq.z, rq.w};
+                        if constexpr (WPREF) {
+                            const uint4 rq = rw[i * WP_I + CI + (CF == 2 ? (j0 / 2) * 4 : 0) + ps];
+                            const unsigned ru[4] = {rq.x, rq.y, rq.z, rq.w};
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { o[2 * k] += __uint_as_float(ru[k] << 16); o[2 * k + 1] += __uint_as_float(ru[k] & 0xffff0000u); }
+                            for (int k = 0; k < 4; ++k) { o[2 * k] += __uint_as_float(ru[k] << 16); o[2 * k + 1] += __uint_as_float(ru[k] & 0xffff0000u); }
+                        }
                         uint4 v;
                         v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
                         const bool ok = m < p.M && ncok;
@@ -1176,7 +1184,7 @@ gemm_conv_kernel(const Params p) {
             for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{}, fl_tag);
             if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{}, fl_tag);
         };
-        bool fastp = WPREF && !f32out && p.epilogue == TMIX_EPI_NONE && !p.rgb && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
+        bool fastp = (WPREF || !Rb) && !f32out && p.epilogue == TMIX_EPI_NONE && !p.rgb && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
         if constexpr (F8C) fastp = fastp && !p.f8copy;
         if (fastp && !sto) chunks(std::integral_constant<int, 1>{});
         else if (fastp) chunks(std::integral_constant<int, 2>{});
@@ -1331,6 +1339,8 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     p.prof = tmix_prof_take(&p.prof_detail);
     tmix_prefetch_take(&p.pf, &p.pf_bytes);
+    { const long long nthr = (long long)grid.x * grid.y * (LW ? LW : WM * WN * KS) * 64, lines = (p.pf_bytes + 127) >> 7;
+      p.pf_per = p.pf ? (int)((lines + nthr - 1) / nthr) : 0; }
     kern<<<grid, (WM * WN * KS + LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;

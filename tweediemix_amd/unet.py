@@ -855,7 +855,7 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
         cur = members[k][0][2].tile_cfg
         best, best_t = cur, base
         for cfg in (cands or L.TILE_CANDIDATES):
-            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 19, 20)):
+            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 18, 19, 20, 21)):
                 continue
             for p, _kind, d in members[k]:
                 d.tile_cfg = cfg
