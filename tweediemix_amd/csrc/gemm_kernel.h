@@ -351,6 +351,18 @@ gemm_conv_kernel(const Params p) {
     float* bias_lds = ln_rs + BM;
     float bias_r = 0.f;
     if (p.bias && tid < BN && n0 + tid < p.N) bias_r = (p.bias + (int64_t)bz * p.strideBias)[n0 + tid];
+    // convolution: the time-embedding row of the tile's image likewise (every tile of this path lies inside one image; a tile that
+    // straddles two row groups takes the generic epilogue, which looks the row up per output row)
+    float* rgb_lds = bias_lds + BN;
+    float rgb_r = 0.f;
+    bool rgb_one = true;
+    if constexpr (CONV) {
+        if (p.rgb) {
+            const int g0 = m0 / p.rows_per_group;
+            rgb_one = (min(m0 + BM, p.M) - 1) / p.rows_per_group == g0;
+            if (rgb_one && tid < BN && n0 + tid < p.N) rgb_r = p.rgb[(int64_t)g0 * p.N + n0 + tid];
+        }
+    }
     constexpr int PU = 16;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     u32x2 lnv[PU];
@@ -371,7 +383,7 @@ gemm_conv_kernel(const Params p) {
     // x = x1 + x2 + x3 (bf16 pieces by truncation, exact residuals): operand halves {x1,x1,x2,0 | x1,x3,x2,0} for -mean
     // and {x1,x2,x1,0 | x3,x1,x2,0} for colsum pair up to the six products x_a * y_b with a + b <= 4 (~24 bits)
     auto ln_reduce = [&]() {
-        if (tid < BN) bias_lds[tid] = bias_r;
+        if (tid < BN) { bias_lds[tid] = bias_r; if constexpr (CONV) rgb_lds[tid] = rgb_r; }
         if (!ln_on) return;
         if (tid < BM) {
             float s1 = 0.f, s2 = 0.f;
@@ -1041,6 +1053,11 @@ gemm_conv_kernel(const Params p) {
                 const bool lnf = p.ln_stats != nullptr;
                 const float4 bq0 = *(const float4*)(bias_lds + wc * TN + j0 * 32 + cc), bq1 = *(const float4*)(bias_lds + wc * TN + j0 * 32 + cc + 4);
                 const float bq[8] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w};
+                float tq[8];                                            // convolution: the image's time-embedding row (zeros without one)
+                if constexpr (CONV) {
+                    const float4 t0 = *(const float4*)(rgb_lds + wc * TN + j0 * 32 + cc), t1 = *(const float4*)(rgb_lds + wc * TN + j0 * 32 + cc + 4);
+                    tq[0] = t0.x; tq[1] = t0.y; tq[2] = t0.z; tq[3] = t0.w; tq[4] = t1.x; tq[5] = t1.y; tq[6] = t1.z; tq[7] = t1.w;
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int mb = m0 + wr * TM + i * 32;
@@ -1059,6 +1076,10 @@ gemm_conv_kernel(const Params p) {
                         float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                         for (int k = 0; k < 8; ++k) o[k] = fmaf(o[k], rs, bq[k]);
+                        if constexpr (CONV) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) o[k] += tq[k];
+                        }
                         if constexpr (WPREF) {
                             const uint4 rq = rw[i * WP_I + CI + (CF == 2 ? (j0 / 2) * 4 : 0) + ps];
                             const unsigned ru[4] = {rq.x, rq.y, rq.z, rq.w};
@@ -1184,7 +1205,7 @@ gemm_conv_kernel(const Params p) {
             for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{}, fl_tag);
             if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{}, fl_tag);
         };
-        bool fastp = (WPREF || !Rb) && !f32out && p.epilogue == TMIX_EPI_NONE && !p.rgb && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
+        bool fastp = (WPREF || !Rb) && !f32out && p.epilogue == TMIX_EPI_NONE && (!p.rgb || (CONV && rgb_one)) && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
         if constexpr (F8C) fastp = fastp && !p.f8copy;
         if (fastp && !sto) chunks(std::integral_constant<int, 1>{});
         else if (fastp) chunks(std::integral_constant<int, 2>{});
@@ -1323,7 +1344,7 @@ constexpr int NUM_CFG = 21;
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
-    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4      // staging ring + fused-LayerNorm block + the tile's bias
+    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4 + (CONV ? BN * 4 : 0)      // staging ring + fused-LayerNorm block + the tile's bias (+ time-embedding row)
                        + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
