@@ -40,7 +40,7 @@ struct AttnParams {
     const bf16_t* K; int64_t ldk, strideK;
     const bf16_t* Vt; int64_t ldvt, strideVt;
     bf16_t* O; int64_t ldo, strideO;
-    int H, Sq, Skv, nq;
+    int B, H, Sq, Skv, nq;
     float scale_log2e;
     unsigned long long* prof; int prof_detail;   // in-situ timing slot (common.h) or NULL
 };
@@ -333,7 +333,11 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
 constexpr int SK_MAX = 96;           // key slots (3 MFMA k-steps of 32)
 constexpr int SQW = 64;              // queries per wave
 
-__global__ void __launch_bounds__(256, 1) attn_small_kernel(const AttnParams p) {
+// The waves of a workgroup share nothing (no LDS, no barrier), so the work is dealt out per WAVE: wave gw of the launch takes queries
+// [64 (gw % nq), +64) of (batch, head) gw / nq, and the host picks the workgroup size -- 4 or 5 waves -- that spreads the waves evenly
+// over the 256 CUs (B = 4, 20 heads, 1024 queries: 1280 waves = 256 workgroups of five, one per CU, where 320 workgroups of four ran
+// 1.25 rounds).
+__global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -341,9 +345,14 @@ __global__ void __launch_bounds__(256, 1) attn_small_kernel(const AttnParams p) 
     unsigned long long pt0 = 0, pt1 = 0;
     if (prof_on) pt0 = prof_enter(p.prof, blockIdx.x == 0, p.prof_detail);
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = bid / p.nq, qt = bid - bh * p.nq;
+    const int gw = bid * (int)(blockDim.x >> 6) + w;           // p.nq = 64-query blocks per (batch, head)
+    const int bh = gw / p.nq, qt = gw - bh * p.nq;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qt * (4 * SQW) + w * SQW;
+    const int q0 = qt * SQW;
+    if (b >= p.B) {                                            // surplus waves of the last workgroup
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt0, pt0);
+        return;
+    }
     const bf16_t* Qb = p.Q + (int64_t)b * p.strideQ + h * 64;
     const bf16_t* Kb = p.K + (int64_t)b * p.strideK + h * 64;
     const bf16_t* Vb = p.Vt + (int64_t)b * p.strideVt + (int64_t)h * 64 * p.ldvt;
@@ -473,14 +482,19 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     p.K = (const bf16_t*)K; p.ldk = ldk; p.strideK = strideK;
     p.Vt = (const bf16_t*)Vt; p.ldvt = ldvt; p.strideVt = strideVt;
     p.O = (bf16_t*)O; p.ldo = ldo; p.strideO = strideO;
-    p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.prof = tmix_prof_take(&p.prof_detail);
     if (Skv <= SK_MAX && !getenv("TMIX_ATTN_GENERAL")) {          // short key set: K / V^T resident in registers, no LDS
-        p.nq = (Sq + 4 * SQW - 1) / (4 * SQW);
-        const int64_t nws = (int64_t)p.nq * B * H;
+        p.nq = (Sq + SQW - 1) / SQW;
+        const int64_t waves = (int64_t)p.nq * B * H;
+        // workgroups of five waves when that fills whole rounds of 256 CUs better than four (waves / CU rounded up, then fewer workgroups)
+        const int64_t w4 = (waves + 3) / 4, w5 = (waves + 4) / 5;
+        const int64_t c4 = ((w4 + 255) / 256) * 4, c5 = ((w5 + 255) / 256) * 5;
+        const int nwv = c5 < c4 ? 5 : 4;
+        const int64_t nws = nwv == 5 ? w5 : w4;
         if (nws > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
-        attn_small_kernel<<<dim3((unsigned)nws), 256, 0, (hipStream_t)stream>>>(p);
+        attn_small_kernel<<<dim3((unsigned)nws), nwv * 64, 0, (hipStream_t)stream>>>(p);
         TMIX_LAUNCH_CHECK();
         return TMIX_OK;
     }
