@@ -188,7 +188,7 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
                                    (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
 def test_gemm_plain(ops, M, N, K, cfg):
@@ -197,7 +197,7 @@ def test_gemm_plain(ops, M, N, K, cfg):
     close(out, a.float() @ w.float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
@@ -209,7 +209,7 @@ def test_gemm_epilogues(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
@@ -223,7 +223,20 @@ def test_gemm_geglu(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+def test_gelu_epilogue_is_the_exact_erf_form_also_in_the_tail(ops):
+    """gelu_erf_f (common.h): Phi(-|x|) = exp2 of a degree-7 fit -- relative accuracy must hold where gelu(x) is tiny (x -> -5),
+    which the rational erf approximation it replaced did not give.  x sweeps [-5.5, 5.5] through an identity weight matrix."""
+    n = 64
+    xs = torch.linspace(-5.5, 5.5, 4096 * n, dtype=torch.float64).reshape(4096, n)
+    a = xs.to(torch.bfloat16).cuda()
+    out = ops.gemm(a, torch.eye(n, dtype=torch.bfloat16).cuda(), act="gelu", tile_cfg=1).float().cpu().double()
+    x = a.float().cpu().double()
+    ref = x * 0.5 * torch.erfc(-x / 2 ** 0.5)                 # exact, no cancellation in the negative tail
+    rel = ((out - ref).abs() / ref.abs().clamp_min(1e-30))[x != 0]
+    assert rel.max().item() < 2 ** -8 * 1.01 + 1e-5, rel.max().item()        # bf16 rounding of the result + 1e-5 of the function itself
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     Bz, M, C = 3, 100, 128
     a = rnd(Bz, M, C, seed=11)
@@ -241,7 +254,7 @@ def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     close(out, big[:, :, C:].float() @ w[0].float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17, 18, 21])
 def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch):
     """the LDS-staged 16-byte stores (default) against the accumulator-layout 8-byte stores (TMIX_NARROW_EPILOGUE=1, the
     fallback for unaligned rows): same values, same operation order per element => identical C, GEGLU output and V^T; the
@@ -276,7 +289,8 @@ def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch)
     torch.testing.assert_close(s[:, 1], (wide[1].float() ** 2).sum(1), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 1, 64, 1), (2, 3, 1000, 77), (1, 2, 70, 96), (2, 2, 300, 33), (1, 20, 1024, 77)])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 1, 64, 1), (2, 3, 1000, 77), (1, 2, 70, 96), (2, 2, 300, 33), (1, 20, 1024, 77),
+                                          (4, 20, 1024, 77), (2, 9, 4096, 77)])     # the last two: five-wave workgroups (the very last with surplus waves)
 def test_short_key_attention_kernel_matches_the_general_one(ops, B, H, Sq, Skv, monkeypatch):
     """attn_small_kernel (K / V^T register-resident, exact softmax; Skv <= 96) vs torch and vs the tiled flash kernel
     (TMIX_ATTN_GENERAL=1) on the same inputs, incl. ragged query counts and a single key."""
@@ -455,7 +469,7 @@ def test_concat_and_embedding_and_linear_small(ops):
         torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15, 20, 21])
 def test_gemm_fused_layernorm_pair(ops, cfg):
     """producer GEMM emits row statistics of what it stored, consumer GEMM applies LayerNorm algebraically:
     together == Linear2(LayerNorm(Linear1(a) + res)) of diffusers' BasicTransformerBlock."""
@@ -724,7 +738,7 @@ def test_gemm_fp8_geglu_output_as_mx_blocks_feeds_the_next_gemm(ops, tile):
     close(out, deq @ ops.dequantize_fp8_rows(w28, sw2).t())
 
 
-@pytest.mark.parametrize("cfg", [7, 12, 16, 18, 20])
+@pytest.mark.parametrize("cfg", [7, 12, 16, 18, 20, 21])
 def test_prefetch_hint_changes_nothing_but_timing(ops, cfg):
     """tmix_gemm_prefetch_next: the launch that consumes the hint touches another tensor while it waits for its own operands --
     its C is bit-identical to the un-hinted launch, the hinted range is only read, and the hint is consumed by ONE launch."""
