@@ -218,7 +218,7 @@ def insitu_profile(tw, reps=3):
         c = by[cls]
         c["launches"] += 1; c["sum_ms"] += d; c["flops"] += fl; c["iv"].append((int(s[0]), int(s[1])))
         if os.environ.get("TMIX_BENCH_SHAPES"):
-            k = key if isinstance(key, tuple) else ((cls, key.batch, key.M, key.N, key.K, key.epilogue, key.tile_cfg) if cls == "gemm"
+            k = key if isinstance(key, tuple) else ((cls, key.batch, key.M, key.N, key.K, key.epilogue, key.tile_cfg) if cls.startswith("gemm")
                                                      else (cls, key.B, key.H, key.W, key.Cin, key.Cout, key.mode, key.tile_cfg))
             shapes[k][0] += 1; shapes[k][1] += d; shapes[k][2] += fl
     for k, (cnt, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
@@ -250,6 +250,26 @@ def insitu_profile(tw, reps=3):
                         avg_launch_us=1e3 * c["sum_ms"] / max(1, c["launches"]), flops=c["flops"],
                         tflops=c["flops"] / max(1e-9, c["sum_ms"]) / 1e9)
     out["instrumented_busy_ms"] = union(all_iv)
+    return out
+
+
+FP8_DENSE_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: dense e4m3 MFMA peak (the headline figures with 2:1 sparsity are not used)
+
+
+def fp8_roofline(prof):
+    """the fp8 plan's own roofline block: its tmix_gemm_fp8 launches (attn1 q/k/v, attn2 to_q, FF1, FF2 of every transformer block)
+    against the dense fp8 MFMA peak, and what stays bf16 in that plan against the bf16 peak -- same in-situ stamps as the headline."""
+    g8, g16 = prof.get("gemm_fp8"), prof.get("gemm")
+    if not g8:
+        return None
+    out = {"bound": "mfma", "kernel": "gemm_conv_kernel<..,PH=2|3> (tmix_gemm_fp8, v_mfma_scale_f32_32x32x64_f8f6f4)",
+           "achieved": g8["tflops"], "peak": FP8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g8["tflops"] / FP8_DENSE_PEAK_TFLOPS,
+           "launches_per_step": g8["launches"], "avg_launch_us": g8["avg_launch_us"], "flops_per_step": g8["flops"],
+           "sum_launch_ms": g8["sum_launch_ms"], "graph_replay_ms": prof["replay_ms"],
+           "classes": {k: {kk: v[kk] for kk in ("launches", "sum_launch_ms", "busy_ms", "avg_launch_us", "tflops")}
+                       for k, v in prof.items() if isinstance(v, dict)}}
+    if g16:
+        out["bf16_gemms_of_this_plan"] = {"launches": g16["launches"], "tflops": g16["tflops"], "frac_of_bf16_peak": g16["tflops"] / BF16_DENSE_PEAK_TFLOPS}
     return out
 
 
@@ -576,6 +596,8 @@ def main(argv=None):
                                         "of 32 emitted by the GEGLU epilogue; everything else bf16",
                             "dtype": "fp8", "value": S_ * args.steps / dt3, "unit": "steps/s", "ms_per_step": 1e3 * dt3 / (args.steps * S_),
                             "parity_check": parity_check(tw3, args, _parts3, primary, device)}
+            if rank == 0:
+                other["fp8"]["roofline"] = fp8_roofline(insitu_profile(tw3))
             del tw3
             torch.cuda.empty_cache()
         if not args.tiny and not args.no_video:
@@ -585,7 +607,8 @@ def main(argv=None):
         flops_step = plan.flops
 
     if rank == 0:
-        g = prof["gemm"]
+        g = prof["gemm"] if args.dtype == "bf16" or "gemm_fp8" not in prof else prof["gemm_fp8"]
+        peak_tf = BF16_DENSE_PEAK_TFLOPS if g is prof.get("gemm") else FP8_DENSE_PEAK_TFLOPS
         pmc = pmc_evidence()
         line = {
             "metric": METRIC, "value": world * S_ * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
@@ -606,8 +629,8 @@ def main(argv=None):
             "unet_tflop_per_step": flops_step / 1e12 / S_,
             "achieved_tflops_whole_step": flops_step / 1e12 / (dt / args.steps),
             "parity_check": check,
-            "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<..,CONV=0> (tmix_gemm_bf16)",
-                         "achieved": g["tflops"], "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / BF16_DENSE_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<..,CONV=0> (tmix_gemm_bf16)" if g is prof.get("gemm") else "gemm_conv_kernel<..,PH=2|3> (tmix_gemm_fp8)",
+                         "achieved": g["tflops"], "peak": peak_tf, "unit": "TFLOP/s", "frac": g["tflops"] / peak_tf,
                          "traffic": pmc[0], "pmc": pmc[1], "algorithmic_bytes_per_launch": alg,
                          "how": "achieved = sum(2MNK of the step's GEMM launches) / sum(their durations), each launch timed on the device clock "
                                 "INSIDE the captured step while the graph replays (concurrent chains included, so the sum can exceed the wall time)",

@@ -7,6 +7,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
 BARGS="--kind lora --no-trajectory --no-cpu-baseline --no-video ${BENCH_EXTRA:-}"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag} -- python bench.py $BARGS > $out/${tag}_bench_line.json 2> $out/bench.log
+# the fp8 plan (--dtype fp8: attn1 q/k/v, attn2 to_q and both FF projections on e4m3 operands) under the same kernel trace
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag}_fp8 -- python bench.py --dtype fp8 $BARGS > $out/${tag}_fp8_bench_line.json 2> $out/bench_fp8.log
 for pm in FETCH_SIZE WRITE_SIZE; do
   # (each counter pass under its own timeout: a pass that hangs costs its own evidence, not the others')
   timeout 600 rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_$pm.log 2>&1
@@ -68,6 +70,7 @@ python - $out $tag <<'PY'
 import json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 man = {"round_tag": tag, "kernel_stats": f"{tag}_kernel_stats.csv", "bench_line": f"{tag}_bench_line.json"}
+if os.path.exists(os.path.join(out, f"{tag}_fp8_kernel_stats.csv")): man["fp8_kernel_stats"] = f"{tag}_fp8_kernel_stats.csv"; man["fp8_bench_line"] = f"{tag}_fp8_bench_line.json"
 for key, f in (("traffic", f"{tag}_traffic.json"), ("mfma_util", f"{tag}_mfma_util.json")):
     if os.path.exists(os.path.join(out, f)): man[key] = f
 json.dump(man, open(os.path.join(out, "MANIFEST.json"), "w"), indent=1)

@@ -549,7 +549,7 @@ class UNetPlan:
         self.flops += fl
         self.gemm_flops += fl
         self.launches["gemm"].append((d, fl))
-        self.op_meta[len(self.ops) - 1] = ("gemm", fl, d)
+        self.op_meta[len(self.ops) - 1] = ("gemm_fp8", fl, d)       # its own class: priced against the fp8 MFMA peak (bench.py)
         if owned:
             self.arena.put(*owned)                  # stream-ordered: free for ops planned after this GEMM
         return out
