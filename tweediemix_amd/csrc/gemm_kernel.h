@@ -43,6 +43,15 @@ static __device__ __forceinline__ float xor32_sum(float x) {      // x + (value 
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// maximum over the four lanes of a quad (the MX block of an e4m3 copy is the 4 adjacent lanes of a row) on DPP quad_perm moves:
+// two VALU instructions instead of two ds_bpermute round trips
+static __device__ __forceinline__ float quad_max(float x) {
+    float y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));      // lane ^ 1
+    x = fmaxf(x, y);
+    y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));            // lane ^ 2
+    return fmaxf(x, y);
+}
+
 struct Params {
     const bf16_t* A; int64_t lda, strideA;
     const bf16_t* W; int64_t ldw, strideW;
@@ -966,7 +975,7 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(u[k] << 16); f[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
                                                           am = fmaxf(am, fmaxf(fabsf(f[2 * k]), fabsf(f[2 * k + 1]))); }
-                            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2));
+                            am = quad_max(am);
                             const int e = e8m0_for_amax(am);
                             const float inv = exp2_neg_int(e);
                             int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
@@ -1036,8 +1045,8 @@ gemm_conv_kernel(const Params p) {
             for (int q = 0; q < 4; ++q) { sa1[i][q] = 0.f; sa2[i][q] = 0.f; }
             sb1[i][0] = sb1[i][1] = sb2[i][0] = sb2[i][1] = 0.f;
         }
-        // FL > 0: the STRAIGHT-LINE form for the common case (bf16 output, no activation, no time-embedding rows, no e4m3 copy; FL = 2
-        // also keeps the row statistics).  With one wave per SIMD the epilogue is bound by VALU issue and by the latencies nobody hides
+        // FL > 0: the STRAIGHT-LINE form for the common case (bf16 output, no activation; FL bit 1 also keeps the row statistics, bit 2
+        // also leaves the e4m3 copy of the stored rows).  With one wave per SIMD the epilogue is bound by VALU issue and by the latencies nobody hides
         // (tools/jobs/r3za_epi_abl.sh: 5.3 of its 6.7 us on 128 x 160 tiles remain with bias loads, residual and stores all removed), and the
         // generic form below has a dozen wave-uniform branches per pass, each a scheduling barrier and a fetch bubble.  Here bias and
         // residual come from registers filled in front of the last K-tile (zeros when the launch has none: x * 1 + 0 and x + 0 leave
@@ -1090,7 +1099,23 @@ gemm_conv_kernel(const Params p) {
                         v.x = pack_bf2(o[0], o[1]); v.y = pack_bf2(o[2], o[3]); v.z = pack_bf2(o[4], o[5]); v.w = pack_bf2(o[6], o[7]);
                         const bool ok = m < p.M && ncok;
                         if (ok) *(uint4*)(Cb + (int64_t)m * p.ldc + nc) = v;
-                        if constexpr (FL == 2) {                        // statistics of the values AS STORED (same order as the generic form)
+                        if constexpr (F8C && (FL & 4) != 0) {           // the e4m3 + MX-block copy of the row AS STORED (as in the generic form)
+                            const unsigned u8[4] = {v.x, v.y, v.z, v.w};
+                            float f[8], am = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(u8[k] << 16); f[2 * k + 1] = __uint_as_float(u8[k] & 0xffff0000u);
+                                                          am = fmaxf(am, fmaxf(fabsf(f[2 * k]), fabsf(f[2 * k + 1]))); }
+                            am = quad_max(am);
+                            const int e = e8m0_for_amax(am);
+                            const float inv = exp2_neg_int(e);
+                            int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
+                            int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, q1, true);
+                            if (ok) {
+                                *(uint2*)(p.f8copy + ((int64_t)bz * p.M + m) * p.ldF8copy + nc) = make_uint2((unsigned)q0, (unsigned)q1);
+                                if ((lane & 3) == 0) p.scale_out[(int64_t)(nc >> 5) * p.ldScaleOut + (int64_t)bz * p.M + m] = (unsigned char)(e + 127);
+                            }
+                        }
+                        if constexpr ((FL & 2) != 0) {                  // statistics of the values AS STORED (same order as the generic form)
                             const unsigned u[4] = {v.x, v.y, v.z, v.w};
                             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -1176,7 +1201,7 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(u8[k] << 16); f[2 * k + 1] = __uint_as_float(u8[k] & 0xffff0000u);
                                                           am = fmaxf(am, fmaxf(fabsf(f[2 * k]), fabsf(f[2 * k + 1]))); }
-                            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2));
+                            am = quad_max(am);
                             const int e = e8m0_for_amax(am);
                             const float inv = exp2_neg_int(e);
                             int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
@@ -1205,11 +1230,13 @@ gemm_conv_kernel(const Params p) {
             for (int c = 0; c < C2; ++c) chunk(c * 2, std::integral_constant<int, 2>{}, fl_tag);
             if constexpr (FN & 1) chunk(FN - 1, std::integral_constant<int, 1>{}, fl_tag);
         };
-        bool fastp = (WPREF || !Rb) && !f32out && p.epilogue == TMIX_EPI_NONE && (!p.rgb || (CONV && rgb_one)) && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
-        if constexpr (F8C) fastp = fastp && !p.f8copy;
-        if (fastp && !sto) chunks(std::integral_constant<int, 1>{});
-        else if (fastp) chunks(std::integral_constant<int, 2>{});
-        else chunks(std::integral_constant<int, 0>{});
+        const bool fastp = (WPREF || !Rb) && !f32out && p.epilogue == TMIX_EPI_NONE && (!p.rgb || (CONV && rgb_one)) && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
+        bool f8q = false;
+        if constexpr (F8C) f8q = p.f8copy != nullptr;
+        // flavour bits: 1 straight-line, 2 row statistics, 4 e4m3 copy
+        if (!fastp) chunks(std::integral_constant<int, 0>{});
+        else if (!f8q) { if (!sto) chunks(std::integral_constant<int, 1>{}); else chunks(std::integral_constant<int, 3>{}); }
+        else { if constexpr (F8C) { if (!sto) chunks(std::integral_constant<int, 5>{}); else chunks(std::integral_constant<int, 7>{}); } }
         if (sto) {
             // a row's partials sit in the lanes that stored its columns: reduce over those lanes (fixed butterfly order), the
             // group's first lane owns the row; the 32-column chunk's owners then add to the same slot (same wave: LDS in order)
