@@ -38,6 +38,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kind", default="both", choices=["both", "lora", "custom"])
+    ap.add_argument("--lora-mode", dest="lora_mode", default="merged", choices=["merged", "lowrank"],
+                    help="lowrank: up(down(x)) as the routed projections' last K-tile (tmix_lora_down + shared weights) instead of merged per-concept weight sets")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the FF / attn1-QKV projections run on e4m3 operands (tmix_gemm_fp8); a separate line, never the headline")
     ap.add_argument("--res", type=int, default=1024)
@@ -68,7 +70,7 @@ def build_sampler(args, kind, device, seed, fp8=None):
     K = 3
     sd = Wt.synthetic_state_dict(cfg, seed=1234, device=device, dtype=torch.bfloat16)
     con = Wt.synthetic_concepts(cfg, kind, K, device=device)
-    W = U.UNetWeights(cfg, sd, device, (kind, con))
+    W = U.UNetWeights(cfg, sd, device, (kind, con), lora_mode=getattr(args, "lora_mode", "merged"))
     g = torch.Generator(device="cpu").manual_seed(42)
     te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g), torch.randn(K + 2, cfg.pooled_dim, generator=g))
     ts = (torch.randn(K, 77, cfg.cross_dim, generator=g), torch.randn(K, cfg.pooled_dim, generator=g))

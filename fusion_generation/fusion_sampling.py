@@ -80,6 +80,8 @@ def build_parser():
     p.add_argument('--no_strict_reference', action='store_true',
                    help='route the concept weights for any concept count (the reference hooks only route when the UNet batch is 4, i.e. 3 concepts)')
     p.add_argument('--streams', type=int, default=1, help='launch chains per UNet call (2: batch rows split over two HIP streams)')
+    p.add_argument('--lora_mode', type=str, default='merged', choices=['merged', 'lowrank'],
+                   help='LoRA deltas as merged per-concept weight sets (default, fastest) or in the reference\'s own low-rank form up(down(x)) (no weight copies)')
     p.add_argument('--no_graphs', action='store_true')
     p.add_argument('--tiny', action='store_true', help='tiny UNet config (smoke tests)')
     return p
@@ -161,7 +163,7 @@ def main(argv=None):
             from tweediemix_amd import text as T
             te, ts, K_text = T.TextPath(opt.sd_path, opt.device).embed(opt, sts)
             assert K_text == K, (K_text, K)
-    W = U.UNetWeights(cfg, sd, opt.device, (kind, con))
+    W = U.UNetWeights(cfg, sd, opt.device, (kind, con), lora_mode=opt.lora_mode)
     h, w = opt.resolution_h // 8, opt.resolution_w // 8
     sidecar = False
     if opt.mask_paths:

@@ -266,6 +266,16 @@ int tmix_softmax_rows_masked(const float* S, int64_t ld_s, void* P, int64_t ld_p
  * O bf16 [(clips*frames)][hw][ldo], columns [0,C). */
 int tmix_temporal_attn(const void* QKV, int64_t ld, void* O, int64_t ldo, int clips, int frames, int64_t hw, int heads,
                        float scale, void* stream);
+/* LoRA in its low-rank form (utils_lora.py:65-79,113-119: batch row i + 1 gets  proj(x) + up_i(down_i(x)), model_lora.py:41-48, rank 4) without
+ * merged per-concept weight copies: the attention projection runs once on shared weights [W | U | 0] over K + 64 input columns, and this
+ * launch fills the 64 PAD columns behind every row of A with that row's down-projections: rows [b * rows_per_set, +rows_per_set) belong to
+ * concept set sets[b] (0 = base, no delta); the P = 4 x (projections fused in the GEMM: 1, or 3 for q|k|v) values  A[m][0..K) . D[set * P + q][0..K)
+ * go to columns K + set * P + q, every other pad column gets 0.  D is bf16 [nsets * P][K], nsets * P <= 64, P in {4, 12}.
+ * Folded LayerNorm (dcolsum / dbias non-NULL; the GEMM then reads raw rows with ln_stats): the pad holds
+ * (x - mean) D'^T + dbias / rstd  with D' = D * gamma as passed in D, dcolsum[i] = sum_k D'[i][k], dbias[i] = sum_k D[i][k] beta[k], and mean / rstd
+ * of the row itself -- so that the GEMM's  rstd * (acc - mean * ln_colsum) + bias  (ln_colsum over the first K columns) adds exactly up(down(LN(x))). */
+int tmix_lora_down(void* A, int64_t lda, int K, int64_t rows, const void* D, int P, int nsets, const float* dcolsum, const float* dbias,
+                   float eps, const int* sets, int64_t rows_per_set, void* stream);
 /* y = clamp(x*scale + shift, lo, hi) on fp32 (image post-processing (img/2+0.5).clamp(0,1), fusion_sampling.py:302) */
 int tmix_affine_clamp(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
 /* out[M,N] = act_out( act_in(in[M,K]) * W[N,K]^T + bias ), fp32 activations, bf16 weights, M <= 256 (16 rows per launch).

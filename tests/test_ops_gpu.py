@@ -757,3 +757,38 @@ def test_prefetch_hint_changes_nothing_but_timing(ops, cfg):
     assert torch.equal(got, ref) and torch.equal(again, ref) and torch.equal(nxt, keep)
     assert lib.tmix_gemm_prefetch_next(nxt.data_ptr(), 1 << 40, st) < 0          # larger than 2 GiB: refused
     L.check(lib.tmix_gemm_prefetch_next(None, 0, st))                            # clears
+
+
+@pytest.mark.parametrize("P,ln", [(4, False), (12, False), (4, True), (12, True)])
+def test_lora_down_fills_the_pad_columns(ops, P, ln):
+    """tmix_lora_down: the row's own concept's down-projections at pad columns [set * P, +P), zeros elsewhere; with a folded
+    LayerNorm the value that the GEMM's rstd * (acc - mean * colsum) turns into up(down(LN(x)))."""
+    K, nsets, S, B = 320, 4, 72, 5
+    sets = torch.tensor([0, 3, 1, 2, 1], dtype=torch.int32).cuda()
+    x = rnd(B * S, K, seed=60) * 1.5 + 0.25
+    a = torch.full((B * S, K + 64), 7.0, dtype=BF).cuda()                 # stale pad contents must be overwritten
+    a[:, :K] = x
+    D = rnd(nsets * P, K, seed=61, scale=0.05)
+    gamma, beta = rnd(K, seed=62, dtype=torch.float32) * 0.2 + 1.0, rnd(K, seed=63, dtype=torch.float32) * 0.1
+    if ln:
+        Dp = (D.float() * gamma).to(BF)
+        ops.lora_down(a, K, Dp, P, nsets, sets, S, dcolsum=Dp.float().sum(1).contiguous(), dbias=(D.float() @ beta).contiguous())
+    else:
+        ops.lora_down(a, K, D, P, nsets, sets, S)
+    assert torch.equal(a[:, :K], x)
+    xf = x.float()
+    ref = torch.zeros(B * S, 64, device="cuda")
+    for b in range(B):
+        s_ = int(sets[b])
+        rows = slice(b * S, (b + 1) * S)
+        if ln:
+            mean = xf[rows].mean(1, keepdim=True)
+            sd = (xf[rows].var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+            Dp32 = (D.float() * gamma).to(BF).float()[s_ * P:(s_ + 1) * P]
+            ref[rows, s_ * P:(s_ + 1) * P] = (xf[rows] - mean) @ Dp32.T + (D.float()[s_ * P:(s_ + 1) * P] @ beta) * sd
+        else:
+            ref[rows, s_ * P:(s_ + 1) * P] = xf[rows] @ D.float()[s_ * P:(s_ + 1) * P].T
+    close(a[:, K:], ref)
+    mask = ref == 0
+    assert (a[:, K:].float()[mask] == 0).all()
+

@@ -14,7 +14,7 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def make(kind, B, h, w, routed, seed=0):
+def make(kind, B, h, w, routed, seed=0, lora_mode="merged"):
     from oracle import unet_oracle as UO
     from tweediemix_amd import unet as U, weights as Wt
     cfg = U.TINY
@@ -39,7 +39,7 @@ def make(kind, B, h, w, routed, seed=0):
                                     for nm in ("q", "k", "v", "out")} for c in con]
         oc = UO.Concepts("lora", lora=lo)
     orc = UO.UNetOracle(UO.TINY, sd, oc)
-    W = U.UNetWeights(cfg, sd, "cuda", (kind, con) if con else None)
+    W = U.UNetWeights(cfg, sd, "cuda", (kind, con) if con else None, lora_mode=lora_mode)
     wsel = list(range(B)) if (routed and B == 4) else [0] * B
     kv = U.KVCache(W, ehs, wsel)
     plan = U.UNetPlan(W, B, h, w, kv, pooled, time_ids, routed=routed)
@@ -66,6 +66,66 @@ def test_unet_plan_matches_oracle(kind, B, routed, hw):
     # replay is deterministic and allocation-free
     eps2 = plan(x.cuda(), t).float().cpu()
     assert torch.equal(eps, eps2)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (8, 24)])
+def test_unet_plan_with_lora_in_low_rank_form_matches_oracle_and_the_merged_plan(hw):
+    """UNetWeights(lora_mode="lowrank"): up(down(x)) as the routed projections' last K-tile (tmix_lora_down fills the pad columns,
+    shared weights [W | U | 0]; utils_lora.py:68,76-77,118) -- same bound against the fp32 oracle as the merged form, no per-concept
+    weight copies, and the two forms agree with each other far inside that bound."""
+    h, w = hw
+    orc, plan, x, ehs, pooled, time_ids = make("lora", 4, h, w, True, lora_mode="lowrank")
+    assert plan.lowrank and not any(k.endswith("_rows") and "kv_rows" not in k for k in plan.W.t)
+    t = 781
+    ref = orc.forward(x, t, ehs, pooled, time_ids, routed=True)
+    eps = plan(x.cuda(), t).float().cpu()
+    r = rel_l2(eps, ref)
+    m = (eps - ref).abs().max().item() / ref.abs().max().item()
+    _orc, plan_m, *_ = make("lora", 4, h, w, True)
+    eps_m = plan_m(x.cuda(), t).float().cpu()
+    print(f"low-rank LoRA {hw}: rel_l2={r:.4g} max_rel={m:.4g}; vs merged plan rel_l2={rel_l2(eps, eps_m):.4g}; launches {len(plan.ops)} vs {len(plan_m.ops)}")
+    assert r <= 2e-2 and m <= 5e-2, (r, m)
+    assert rel_l2(eps, eps_m) <= 1e-2
+    # an unrouted call of the same weights (outside the window): no deltas at all == the base network
+    orc0, plan0, *_ = make("lora", 4, h, w, False, lora_mode="lowrank")
+    assert not plan0.lowrank
+    ref0 = orc0.forward(x, t, ehs, pooled, time_ids, routed=False)
+    assert rel_l2(plan0(x.cuda(), t).float().cpu(), ref0) <= 2e-2
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.01])
+def test_lora_low_rank_form_resolves_deltas_below_the_ulp_of_w(scale):
+    """the same 1280-wide projection as test_lora_delta_merged_into_bf16_weights through the low-rank path (tmix_lora_down + one GEMM over
+    K + 64 columns): the delta's own contribution -- low-rank output minus base output -- is exact to bf16 operand rounding (~1 %) at the
+    checkpoints' delta size AND at deltas 100x smaller, where the merged form only dithers it (~0.9 relative error)."""
+    from tweediemix_amd import ops
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 1024, 1280, 1280
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W32 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    down = (torch.randn(4, K, generator=g) * 0.25).cuda()
+    up = (torch.randn(N, 4, generator=g) * 0.02 * scale).cuda()
+    y_delta = (x.float() @ down.T) @ up.T
+    def f32_gemm(a_, w_):                                         # fp32 C (TMIX_EPI_F32OUT): the OUTPUT rounding to bf16 would bury a small delta in either form
+        o = torch.empty(a_.shape[0], w_.shape[0], dtype=torch.float32, device="cuda")
+        ops.gemm(a_, w_, out_f32=o)
+        return o
+    y_base = f32_gemm(x, W32.to(torch.bfloat16))
+    y_merged = f32_gemm(x, (W32 + up @ down).to(torch.bfloat16))
+    a = torch.zeros(M, K + 64, dtype=torch.bfloat16).cuda()
+    a[:, :K] = x
+    D = torch.zeros(8, K).cuda()
+    D[4:] = down                                                   # set 0 = base (zeros), set 1 = the concept
+    U = torch.zeros(N, 64).cuda()
+    U[:, 4:8] = up
+    ops.lora_down(a, K, D.to(torch.bfloat16).contiguous(), 4, 2, torch.tensor([1], dtype=torch.int32).cuda(), M)
+    y_lr = f32_gemm(a, torch.cat([W32, U], 1).to(torch.bfloat16).contiguous())
+    e_lr = rel_l2(y_lr - y_base, y_delta)
+    e_m = rel_l2(y_merged - y_base, y_delta)
+    print(f"delta scale {scale}: contribution error low-rank {e_lr:.3g}, merged {e_m:.3g}  (|delta|/|W| = {(up @ down).abs().mean().item() / W32.abs().mean().item():.2g})")
+    assert e_lr < 2e-2                                             # bf16 rounding of T = x down^T and of up: ~2^-9 each
+    if scale < 1.0:
+        assert e_m > 0.5                                           # the merged form has only dithered the delta into W
 
 
 def test_kv_cache_routing_exact():
@@ -240,7 +300,7 @@ def _oracle_concepts(kind, con):
     return UO.Concepts("lora", lora=lo)
 
 
-def _timed_plan(sd, kind, hw, streams, fp8=False):
+def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged"):
     """the fusion-phase UNet plan EXACTLY as bench.py's timed region builds it: bench.build_sampler's Tweediemix (same flags,
     prompt rows uncond + K concepts, concept routing, `streams` launch chains, shipped tile table) -> tw.plan("fusion"), i.e.
     sampler.Tweediemix._build_plan: one UNetPlan at B = 4 with routed row_sets for streams = 1 (the default), a PlanGroup of
@@ -248,7 +308,7 @@ def _timed_plan(sd, kind, hw, streams, fp8=False):
     from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
     cfg, K = U.SDXL, 3
     con = Wt.synthetic_concepts(cfg, kind, K, device="cuda")
-    W = U.UNetWeights(cfg, sd, "cuda", (kind, con))
+    W = U.UNetWeights(cfg, sd, "cuda", (kind, con), lora_mode=lora_mode)
     g = torch.Generator().manual_seed(5)
     te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float(), torch.randn(K + 2, cfg.pooled_dim, generator=g))
     ts = (torch.randn(K, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float(), torch.randn(K, cfg.pooled_dim, generator=g))
@@ -304,6 +364,24 @@ def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, s
     r = rel_l2(eps, ref)
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
     print(f"SDXL {kind} {hw * 8}^2 B=4, {streams} chain(s), graph replay: rel_l2={r:.4g} max_rel={m:.4g} tilings={U.used_tilings(plan)}")
+    assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)
+
+
+def test_low_rank_lora_full_size_sdxl_vs_oracle(sdxl_weights):
+    """`--lora_mode lowrank` at the REAL SDXL widths (2.57 B parameters, 280 routed projections each behind a tmix_lora_down launch,
+    shared weights over K + 64 columns), latent 64 x 64, B = 4 concept-routed rows, the sampler's own plan builder, hipGraph replay,
+    against the fp32 oracle: the bf16 bound of the merged form (rel L2 <= 2e-2)."""
+    from oracle import unet_oracle as UO
+    from tweediemix_amd import unet as U
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, "lora", 64, 1, lora_mode="lowrank")
+    assert plan.lowrank and not plan.routed
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 4, 64, 64, generator=g).repeat(4, 1, 1, 1).cuda()
+    eps = _graph_replay(plan, x, 601)
+    ref = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts("lora", con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    r = rel_l2(eps, ref)
+    m = (eps - ref).abs().max().item() / ref.abs().max().item()
+    print(f"SDXL lora (low-rank form) 512^2 B=4, one chain, graph replay: rel_l2={r:.4g} max_rel={m:.4g}")
     assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)
 
 

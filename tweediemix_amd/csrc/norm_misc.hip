@@ -578,6 +578,109 @@ extern "C" int tmix_concat_channels(const void* X1, int C1, const void* X2, int 
     return TMIX_OK;
 }
 
+// ------------------------------------------------------------------------------ LoRA down-projection (low-rank form of the concept deltas)
+// utils_lora.py:65-79,113-119 add `up(down(x))` of concept i to batch row i + 1 of every attention projection (model_lora.py:41-48,
+// rank 4).  In the low-rank mode (UNetWeights(lora_mode="lowrank")) the projection runs ONCE on shared weights [W | U | 0] with
+// K + 64 input columns: the 64 pad columns behind a row of A hold that row's down-projections -- the P = 4 x (projections fused in the
+// GEMM) values of the row's OWN concept at columns K + set * P .., zeros elsewhere -- so the GEMM's last K-tile adds up(down(x)) and no
+// merged per-concept weight copies exist.  This kernel fills the pad.  With a LayerNorm folded into the GEMM (ln != 0) the GEMM forms
+// rstd * (acc - mean * colsum(W')) + bias with colsum over the first K columns only, so the pad must hold T / rstd where
+// T = LN(x) D^T:  (x - mean) D'^T + (D beta) / rstd  with D' = D * gamma; mean / rstd are taken from the row itself (fp32, E[x^2] - mean^2,
+// the same definition the GEMM's statistics use).  One wave owns R consecutive rows (same concept), lanes split K in 16-byte pieces.
+namespace {
+template <int P, int R>
+__global__ void __launch_bounds__(256) lora_down_kernel(bf16_t* __restrict__ A, int64_t lda, int K, int64_t rows, const bf16_t* __restrict__ D,
+                                                        const float* __restrict__ dcolsum, const float* __restrict__ dbias, float eps, int ln,
+                                                        const int* __restrict__ sets, int64_t rows_per_set) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t m0 = wv * R;
+    if (m0 >= rows) return;
+    const int set = sets[m0 / rows_per_set];
+    const bf16_t* Ds = D + (int64_t)set * P * K;
+    float acc[R][P], s1[R], s2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s1[r] = 0.f; s2[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < P; ++q) acc[r][q] = 0.f;
+    }
+    const int nch = K >> 3;
+    for (int c = lane; c < nch; c += 64) {
+        float a[R][8];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t m = m0 + r < rows ? m0 + r : rows - 1;
+            const uint4 v = *(const uint4*)(A + m * lda + c * 8);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[r][2 * k] = __uint_as_float(u[k] << 16); a[r][2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1[r] += a[r][k]; s2[r] = fmaf(a[r][k], a[r][k], s2[r]); }
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const uint4 v = *(const uint4*)(Ds + (int64_t)q * K + c * 8);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+            float d[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[r][q] = fmaf(a[r][k], d[k], acc[r][q]);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s1[r] += __shfl_xor(s1[r], off); s2[r] += __shfl_xor(s2[r], off);
+#pragma unroll
+            for (int q = 0; q < P; ++q) acc[r][q] += __shfl_xor(acc[r][q], off);
+        }
+    }
+    // lane l writes pad column l of every row: the row's own values at [set * P, set * P + P), zeros elsewhere
+    const int q_of_lane = lane - set * P;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (m0 + r >= rows) break;
+        float mean = 0.f, sd = 1.f;
+        if (ln) {
+            mean = s1[r] / (float)K;
+            sd = sqrtf(fmaxf(s2[r] / (float)K - mean * mean, 0.f) + eps);          // 1 / rstd
+        }
+        float x = 0.f;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q == q_of_lane) x = ln ? acc[r][q] - mean * dcolsum[set * P + q] + dbias[set * P + q] * sd : acc[r][q];
+        A[(m0 + r) * lda + K + lane] = f2bf(x);
+    }
+}
+}  // namespace
+
+extern "C" int tmix_lora_down(void* A, int64_t lda, int K, int64_t rows, const void* D, int P, int nsets, const float* dcolsum,
+                              const float* dbias, float eps, const int* sets, int64_t rows_per_set, void* stream) {
+    if (!A || !D || !sets) TMIX_FAIL(TMIX_EINVAL, "lora_down: null pointer");
+    if (rows <= 0 || K <= 0 || (K % 8) || lda < K + 64 || (lda % 8)) TMIX_FAIL(TMIX_ESHAPE, "lora_down: rows=%lld K=%d lda=%lld (rows carry 64 pad columns behind their K values)", (long long)rows, K, (long long)lda);
+    if ((P != 4 && P != 12) || nsets < 1 || nsets * P > 64) TMIX_FAIL(TMIX_ESHAPE, "lora_down: P=%d (4 or 12) x nsets=%d must fit the 64 pad columns", P, nsets);
+    if ((dcolsum == nullptr) != (dbias == nullptr)) TMIX_FAIL(TMIX_EINVAL, "lora_down: the folded-LayerNorm form needs dcolsum and dbias");
+    if (!aligned16(A) || !aligned16(D)) TMIX_FAIL(TMIX_EALIGN, "lora_down: A / D must be 16-byte aligned");
+    const int ln = dcolsum != nullptr;
+    if (rows_per_set <= 0) TMIX_FAIL(TMIX_ESHAPE, "lora_down: rows_per_set=%lld", (long long)rows_per_set);
+    // rows per wave: as many as divide a concept's row block (its rows share one set of down matrices)
+    const int R = (P == 4 && rows_per_set % 8 == 0) ? 8 : rows_per_set % 4 == 0 ? 4 : rows_per_set % 2 == 0 ? 2 : 1;
+    const int64_t waves = (rows + R - 1) / R;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+#define TMIX_LORA_DOWN(PP, RR) lora_down_kernel<PP, RR><<<grid, 256, 0, st>>>((bf16_t*)A, lda, K, rows, (const bf16_t*)D, dcolsum, dbias, eps, ln, sets, rows_per_set)
+    if (P == 12) { if (R == 4) TMIX_LORA_DOWN(12, 4); else if (R == 2) TMIX_LORA_DOWN(12, 2); else TMIX_LORA_DOWN(12, 1); }
+    else { if (R == 8) TMIX_LORA_DOWN(4, 8); else if (R == 4) TMIX_LORA_DOWN(4, 4); else if (R == 2) TMIX_LORA_DOWN(4, 2); else TMIX_LORA_DOWN(4, 1); }
+#undef TMIX_LORA_DOWN
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
 // ------------------------------------------------------------------------------ temporal attention (frame axis, S <= 16)
 // I2VGen-XL's TransformerTemporalModel attends over the FRAMES of one pixel: sequences of 16 tokens, head size 64, one
 // (clip, pixel, head) item per wave.  Lane = (query frame i = lane & 15, 16-wide slice c = lane >> 4 of the head dimension).

@@ -91,6 +91,7 @@ SIGNATURES = {
     "tmix_gemm_tile_shape": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tmix_gemm_stats_parts": (C.c_int, [C.c_int, C.c_int]),
     "tmix_concat_channels": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, i64, vp]),
+    "tmix_lora_down": (C.c_int, [vp, i64, C.c_int, i64, vp, C.c_int, C.c_int, vp, vp, f32, vp, i64, vp]),
     "tmix_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "tmix_linear_small": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tmix_linear_small_sections": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

@@ -70,7 +70,7 @@ def stats_parts(N, tile_cfg):
 
 def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows_per_group=0, geglu=False,
                    out_t=None, n_trans_begin=-1, tile_cfg=0, row_stats_out=None, ln_stats=None, ln_colsum=None,
-                   ln_eps=1e-5, ln_parts=0, act=None, out_f32=None):
+                   ln_eps=1e-5, ln_parts=0, act=None, out_f32=None, ln_k=None):
     """a [batch?,M,K] bf16 (last dim contiguous), w [batch?,N,K] bf16, out [batch?,M,N'] bf16."""
     a3 = a if a.dim() == 3 else a.unsqueeze(0)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -122,7 +122,7 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
         d.ln_stats, d.strideLnStats, d.ldLnStats = st.data_ptr(), 2 * M, st.shape[1]
         d.ln_parts = int(ln_parts) if ln_parts else st.shape[0]
         d.ln_colsum, d.strideLnColsum = ln_colsum.data_ptr(), (N if ln_colsum.dim() == 2 and batch > 1 else 0)
-        d.ln_inv_c, d.ln_eps = 1.0 / K, ln_eps
+        d.ln_inv_c, d.ln_eps = 1.0 / (ln_k or K), ln_eps       # ln_k: the LayerNorm's width when A carries extra columns behind it (low-rank LoRA pad)
     return d
 
 
@@ -434,3 +434,17 @@ def softmax_rows_masked(scores, probs, valid, scale):
     L.check(L.load().tmix_softmax_rows_masked(_p(scores), scores.stride(0), _p(probs), probs.stride(0), rows, cols, int(valid),
                                               float(scale), _stream()), "tmix_softmax_rows_masked")
     return probs
+
+
+def lora_down(a_pad, K, D, P, nsets, sets, rows_per_set, dcolsum=None, dbias=None, eps=1e-5):
+    """fill the 64 pad columns behind the K values of every row of a_pad [rows, K + 64] (bf16, in place) with the rows' LoRA
+    down-projections (tmix_lora_down); sets: int32 device tensor, one concept set per block of rows_per_set rows."""
+    _need_cuda(a_pad, D, sets)
+    assert a_pad.dtype == BF16 and a_pad.dim() == 2 and a_pad.stride(1) == 1 and a_pad.shape[1] >= K + 64 and sets.dtype == torch.int32
+    assert D.dtype == BF16 and D.is_contiguous() and D.shape == (nsets * P, K)
+    lib = L.load()
+    L.check(lib.tmix_lora_down(a_pad.data_ptr(), a_pad.stride(0), K, a_pad.shape[0], D.data_ptr(), P, nsets,
+                               None if dcolsum is None else dcolsum.data_ptr(), None if dbias is None else dbias.data_ptr(), eps,
+                               sets.data_ptr(), rows_per_set, _stream()), "tmix_lora_down")
+    return a_pad
+

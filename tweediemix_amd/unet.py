@@ -114,10 +114,16 @@ class UNetWeights:
               '<tb>.attnN.processor.to_{q,k,v,out}_lora.{down,up}.weight' (fusion_sampling_lora.py:207-210).
     """
 
-    def __init__(self, cfg: UNetConfig, sd: dict, device="cuda", concepts=None):
+    def __init__(self, cfg: UNetConfig, sd: dict, device="cuda", concepts=None, lora_mode="merged"):
+        """lora_mode (kind 'lora' only): "merged" -- one bf16 weight set W + up @ down per concept and projection, picked per batch row
+        by the batched GEMM (the default: fastest; +4.9 GB at K = 3, and a delta below ulp_bf16(W) is only dithered into W) -- or
+        "lowrank" -- the reference's own form up(down(x)) (utils_lora.py:68,76-77,118): shared weights [W | U | 0] over K + 64 input
+        columns, the rows' down-projections written into the 64 pad columns by tmix_lora_down in front of every routed projection."""
         self.cfg, self.device = cfg, torch.device(device)
         self.kind = concepts[0] if concepts else "none"
         self.K = len(concepts[1]) if concepts else 0
+        assert lora_mode in ("merged", "lowrank")
+        self.lora_mode = lora_mode if self.kind == "lora" else "merged"
         self._fp8 = {}
         self._tproj = None
         dev = self.device
@@ -160,6 +166,33 @@ class UNetWeights:
                     rows.append(rows[0])
             return torch.stack(rows)
 
+        def lowrank(key, base, a, whiches, norm=None):
+            """the low-rank form of projection `key` (base weight [N, Kin], already LayerNorm-folded when norm is given): t[key + ".lr"] =
+            [W | U | 0] bf16 [N, Kin + 64] and the stacked down matrices D [(1 + K) * P, Kin] (set 0 = base: zeros), P = 4 per fused
+            projection in `whiches`; column Kin + (set * len(whiches) + c) * 4 + r pairs rank r of concept `set`'s projection c."""
+            nw, nsets = len(whiches), 1 + len(lora)
+            P = 4 * nw
+            assert nsets * P <= 64, "low-rank LoRA: (1 + concepts) x 4 x fused projections must fit the 64 pad columns"
+            N, Kin = base.shape
+            n1 = N // nw
+            U = torch.zeros(N, 64, device=dev, dtype=F32)
+            Dm = torch.zeros(nsets * P, Kin, device=dev, dtype=F32)
+            for si, csd in enumerate(lora):
+                for c, which in enumerate(whiches):
+                    kd, ku = f"{a}.processor.to_{which}_lora.down.weight", f"{a}.processor.to_{which}_lora.up.weight"
+                    if kd in csd and ku in csd:
+                        col = ((si + 1) * nw + c) * 4
+                        U[c * n1:(c + 1) * n1, col:col + 4] = csd[ku].to(dev, F32)
+                        Dm[(si + 1) * P + c * 4:(si + 1) * P + c * 4 + 4] = csd[kd].to(dev, F32)
+            t[key + ".lr"] = torch.cat([base.to(dev, BF16), U.to(BF16)], dim=1).contiguous()
+            if norm is not None:                      # T = LN(x) D^T through the GEMM's folded LayerNorm: see tmix_lora_down
+                gm, bt = g(norm + ".weight").to(F32), g(norm + ".bias").to(F32)
+                Dp = (Dm * gm).to(BF16)
+                t[key + ".lr.D"], t[key + ".lr.dcolsum"], t[key + ".lr.dbias"] = Dp.contiguous(), Dp.float().sum(1).contiguous(), (Dm @ bt).contiguous()
+            else:
+                t[key + ".lr.D"] = Dm.to(BF16).contiguous()
+            t[key + ".lr.P"] = P
+
         def fold(key, w, norm, bias=None):
             """store Linear(LayerNorm(.)) folded for tmix_gemm_desc.ln_*: W*gamma, its column sums and W@beta (+bias)."""
             wp, cs, tt = fold_layernorm(w.to(dev, F32), g(norm + ".weight"), g(norm + ".bias"), bias)
@@ -181,13 +214,19 @@ class UNetWeights:
             if lora is not None:
                 mk = merged(g(a2 + ".to_k.weight"), a2, "k")
                 mv = merged(g(a2 + ".to_v.weight"), a2, "v")
-                kv_rows = [torch.cat([mk[i], mv[i]]) for i in range(mk.shape[0])]
-                fold(a1 + ".qkv_rows", torch.cat([merged(g(a1 + ".to_q.weight"), a1, "q"),
-                                                  merged(g(a1 + ".to_k.weight"), a1, "k"),
-                                                  merged(g(a1 + ".to_v.weight"), a1, "v")], dim=1), n1)
-                t[a1 + ".out_rows"] = bf(merged(g(a1 + ".to_out.0.weight"), a1, "out"))
-                fold(a2 + ".q_rows", merged(g(a2 + ".to_q.weight"), a2, "q"), n2)
-                t[a2 + ".out_rows"] = bf(merged(g(a2 + ".to_out.0.weight"), a2, "out"))
+                kv_rows = [torch.cat([mk[i], mv[i]]) for i in range(mk.shape[0])]     # attn2 K / V: projected once per call kind (KVCache), merged in fp32
+                if self.lora_mode == "lowrank":
+                    lowrank(a1 + ".qkv", t[a1 + ".qkv"], a1, ("q", "k", "v"), n1)
+                    lowrank(a1 + ".out", t[a1 + ".out"], a1, ("out",))
+                    lowrank(a2 + ".q", t[a2 + ".q"], a2, ("q",), n2)
+                    lowrank(a2 + ".out", t[a2 + ".out"], a2, ("out",))
+                else:
+                    fold(a1 + ".qkv_rows", torch.cat([merged(g(a1 + ".to_q.weight"), a1, "q"),
+                                                      merged(g(a1 + ".to_k.weight"), a1, "k"),
+                                                      merged(g(a1 + ".to_v.weight"), a1, "v")], dim=1), n1)
+                    t[a1 + ".out_rows"] = bf(merged(g(a1 + ".to_out.0.weight"), a1, "out"))
+                    fold(a2 + ".q_rows", merged(g(a2 + ".to_q.weight"), a2, "q"), n2)
+                    t[a2 + ".out_rows"] = bf(merged(g(a2 + ".to_out.0.weight"), a2, "out"))
             t[a2 + ".kv_rows"] = bf(torch.stack(kv_rows))       # [1 or 1+K, 2C, cross]
             wp, cs, tt = fold_layernorm(g(tb + ".ff.net.0.proj.weight").to(F32), g(n3 + ".weight"), g(n3 + ".bias"),
                                         g(tb + ".ff.net.0.proj.bias"))
@@ -346,6 +385,13 @@ class UNetPlan:
         # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
         self.row_sets = list(row_sets) if row_sets is not None else list(range(B))
         self.routed = bool(routed) and W.kind == "lora" and len(self.row_sets) == B and max(self.row_sets) <= W.K
+        # low-rank LoRA (UNetWeights.lora_mode): the routed projections run on SHARED weights over K + 64 input columns; the concept of a
+        # batch row only decides what tmix_lora_down writes into the pad columns of its rows
+        self.lowrank = self.routed and getattr(W, "lora_mode", "merged") == "lowrank"
+        if self.lowrank:
+            assert not self.fp8, "low-rank LoRA runs the bf16 projections only"
+            self.routed = False
+            self._sets_dev = torch.tensor(self.row_sets, device=W.device, dtype=torch.int32)
         self._rows_cache = {}
         self.lib = L.load()
         self.dev = W.device
@@ -624,13 +670,30 @@ class UNetPlan:
             A.put(sc)
         return out
 
-    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, fp8=False, a8=None, **kw):
+    def _proj(self, a, key, out, S, Cin, ln=None, stats_out=None, fp8=False, a8=None, a_full=None, **kw):
         """Linear over [B,S,Cin] tokens: per-row merged weights when LoRA-routed, else one shared GEMM.
         ln: statistics of a LayerNorm folded into this projection (weights stored folded, see UNetWeights.fold);
         stats_out: accumulate the statistics of the rows this projection writes."""
         W = self.W
         batched = self.routed or kw.get("out_t") is not None    # transposed V is per batch row -> keep the batch dimension
         shp = (self.B, S) if batched else (self.B * S,)
+        if self.lowrank and (key + ".lr") in W.t:
+            # up(down(x)) as the projection's last K-tile: the pad columns behind the rows of `a` (a_full = the [B, S, Cin + 64] buffer `a`
+            # is a view of) receive the rows' down-projections, then ONE shared GEMM over Cin + 64 columns
+            assert a_full is not None and a_full.shape[-1] == Cin + 64 and a_full.data_ptr() == a.data_ptr()
+            a2 = a_full.view(self.B * S, Cin + 64)
+            lnk = ln is not None
+            self._emit(self.lib.tmix_lora_down, a2.data_ptr(), a2.stride(0), Cin, self.B * S, W[key + ".lr.D"].data_ptr(), W[key + ".lr.P"],
+                       1 + W.K, W[key + ".lr.dcolsum"].data_ptr() if lnk else None, W[key + ".lr.dbias"].data_ptr() if lnk else None,
+                       1e-5, self._sets_dev.data_ptr(), S)
+            if lnk:
+                kw["ln_stats"], kw["ln_colsum"], kw["bias"] = ln, W[key + ".colsum"], W[key + ".bias"]
+            if stats_out is not None:
+                kw["row_stats_out"] = stats_out
+            if kw.get("residual") is not None:
+                kw["residual"] = kw["residual"].view(*shp, kw["residual"].shape[-1])
+            kw["ln_k"] = Cin if lnk else None
+            return self._gemm(a_full.view(*shp, Cin + 64), W[key + ".lr"], out.view(*shp, out.shape[-1]), **kw)
         if ln is not None:
             kw["ln_stats"] = ln
             kw["ln_colsum"] = self._rows(key, ".colsum") if self.routed else W[key + ".colsum"]
@@ -659,7 +722,9 @@ class UNetPlan:
         S = Hh * Ww
         H = Cc // self.cfg.head_dim
         g = self._gn(x, Cc, S, name + ".norm", 1e-6, False)
-        h = A.get(B, S, Cc)
+        pad = 64 if self.lowrank else 0              # low-rank LoRA: 64 pad columns behind every row that feeds a routed projection
+        h_full = A.get(B, S, Cc + pad)
+        h = h_full[:, :, :Cc] if pad else h_full
         st = self._ln_stats(S, Cc)
         # fp8 plans: every GEMM that writes the residual stream h also leaves its e4m3 + MX-block copy (TMIX_F8_COPY_OUT), which the
         # next projection (attn1 q/k/v, attn2 to_q, FF1) reads as its A operand -- no quantiser launches inside a block
@@ -676,20 +741,22 @@ class UNetPlan:
             a1, a2 = tb + ".attn1", tb + ".attn2"
             # --- self attention; norm1 is folded into the q/k/v projection
             qk = A.get(B, S, 2 * Cc)
-            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc, fp8=True, a8=h8)
-            ao = A.get(B, S, Cc)
+            self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc, fp8=True, a8=h8, a_full=h_full)
+            ao_full = A.get(B, S, Cc + pad)
+            ao = ao_full[:, :, :Cc] if pad else ao_full
             self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
             A.put(qk)
-            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8)
-            A.put(ao)
+            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
+            A.put(ao_full)
             # --- cross attention against the cached K / V^T; norm2 folded into to_q
             q = A.get(B, S, Cc)
-            self._proj(h, a2 + ".q", q, S, Cc, ln=st, fp8=h8 is not None, a8=h8)
-            ao = A.get(B, S, Cc)
+            self._proj(h, a2 + ".q", q, S, Cc, ln=st, fp8=h8 is not None, a8=h8, a_full=h_full)
+            ao_full = A.get(B, S, Cc + pad)
+            ao = ao_full[:, :, :Cc] if pad else ao_full
             self._attn(q, self.kv.k[a2], self.kv.vt[a2], ao, H, S, self.kv.Lk)
             A.put(q)
-            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8)
-            A.put(ao)
+            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
+            A.put(ao_full)
             # --- feed forward: norm3 folded into the first GEMM, GEGLU fused in its epilogue
             if self.fp8 and self.fp8_chain_ff:
                 # the intermediate leaves FF1 as e4m3 with one E8M0 scale per 32 columns and FF2 reads it as block-scaled A
@@ -711,7 +778,7 @@ class UNetPlan:
         out = A.get(B, S, Cc)
         self._gemm(h.view(B * S, Cc), W[name + ".proj_out.weight"], out.view(B * S, Cc), bias=W[name + ".proj_out.bias"],
                    residual=x.view(B * S, Cc))
-        A.put(h)
+        A.put(h_full)
         if h8 is not None:
             A.put(h8buf)
         return out
