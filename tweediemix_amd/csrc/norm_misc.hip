@@ -586,75 +586,85 @@ extern "C" int tmix_concat_channels(const void* X1, int C1, const void* X2, int 
 // merged per-concept weight copies exist.  This kernel fills the pad.  With a LayerNorm folded into the GEMM (ln != 0) the GEMM forms
 // rstd * (acc - mean * colsum(W')) + bias with colsum over the first K columns only, so the pad must hold T / rstd where
 // T = LN(x) D^T:  (x - mean) D'^T + (D beta) / rstd  with D' = D * gamma; mean / rstd are taken from the row itself (fp32, E[x^2] - mean^2,
-// the same definition the GEMM's statistics use).  One wave owns R consecutive rows (same concept), lanes split K in 16-byte pieces.
+// the same definition the GEMM's statistics use).
 namespace {
-template <int P, int R>
+typedef __attribute__((ext_vector_type(8))) __bf16 lora_frag;
+// One workgroup = 16 rows of A, its four waves split K: per 32-wide k-step a wave issues v_mfma_f32_16x16x32_bf16 twice --
+//   C1[i][j] += sum_k Dx[i][k] X[j][k]   Dx = the concept's P down rows, then one row of ones (row P: the row sum s1), zeros
+//   C2[i][j] += sum_k X[i][k] X[j][k]    the Gram matrix of the 16 rows: its diagonal is the sum of squares s2 (exact: bf16 products, fp32 sums)
+// -- both operands straight from global memory in MFMA layout (lane = (row, k-quarter): 16 bytes), no cross-lane reduction; the waves'
+// partial tiles are added through LDS and wave 0 writes the 64 pad columns of its 16 rows.
+template <int P>
 __global__ void __launch_bounds__(256) lora_down_kernel(bf16_t* __restrict__ A, int64_t lda, int K, int64_t rows, const bf16_t* __restrict__ D,
                                                         const float* __restrict__ dcolsum, const float* __restrict__ dbias, float eps, int ln,
                                                         const int* __restrict__ sets, int64_t rows_per_set) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t m0 = wv * R;
-    if (m0 >= rows) return;
-    const int set = sets[m0 / rows_per_set];
-    const bf16_t* Ds = D + (int64_t)set * P * K;
-    float acc[R][P], s1[R], s2[R];
+    __shared__ float red[3][2][4][64];                      // waves 1-3: C1 / C2 partials, [reg][lane]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    // blocks of 16 rows never cross a concept boundary: block = (batch row bb, 16-row piece of its rows_per_set rows)
+    const int bps = (int)((rows_per_set + 15) >> 4);
+    const int64_t bb = blockIdx.x / bps, m0 = bb * rows_per_set + (int64_t)(blockIdx.x - bb * bps) * 16;
+    const int64_t mend = (bb + 1) * rows_per_set;           // (rows == batch rows x rows_per_set)
+    const int set = sets[bb];
+    const int64_t mrow = m0 + j < mend ? m0 + j : mend - 1;
+    const bf16_t* xr = A + mrow * lda + kq * 8;
+    const bf16_t* dr = D + ((int64_t)set * P + (j < P ? j : 0)) * K + kq * 8;
+    lora_frag ones;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        s1[r] = 0.f; s2[r] = 0.f;
+    for (int k = 0; k < 8; ++k) ones[k] = (__bf16)1.0f;
+    lora_frag zero;
 #pragma unroll
-        for (int q = 0; q < P; ++q) acc[r][q] = 0.f;
+    for (int k = 0; k < 8; ++k) zero[k] = (__bf16)0.0f;
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1;
+    const int nks = K >> 5;                                  // 32-wide k-steps; wave w takes every fourth
+    for (int ks = w; ks < nks; ks += 4) {
+        const lora_frag x = *(const lora_frag*)(xr + ks * 32);
+        lora_frag d = j < P ? *(const lora_frag*)(dr + ks * 32) : (j == P ? ones : zero);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d, x, c1, 0, 0, 0);      // lane (column j = data row, rows 4 kq + r = down row)
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, x, c2, 0, 0, 0);
     }
-    const int nch = K >> 3;
-    for (int c = lane; c < nch; c += 64) {
-        float a[R][8];
+    if (w) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t m = m0 + r < rows ? m0 + r : rows - 1;
-            const uint4 v = *(const uint4*)(A + m * lda + c * 8);
-            const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { a[r][2 * k] = __uint_as_float(u[k] << 16); a[r][2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { s1[r] += a[r][k]; s2[r] = fmaf(a[r][k], a[r][k], s2[r]); }
-        }
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const uint4 v = *(const uint4*)(Ds + (int64_t)q * K + c * 8);
-            const unsigned u[4] = {v.x, v.y, v.z, v.w};
-            float d[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { d[2 * k] = __uint_as_float(u[k] << 16); d[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[r][q] = fmaf(a[r][k], d[k], acc[r][q]);
-        }
+        for (int r = 0; r < 4; ++r) { red[w - 1][0][r][lane] = c1[r]; red[w - 1][1][r][lane] = c2[r]; }
     }
+    __syncthreads();
+    if (w) return;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s1[r] += __shfl_xor(s1[r], off); s2[r] += __shfl_xor(s2[r], off);
-#pragma unroll
-            for (int q = 0; q < P; ++q) acc[r][q] += __shfl_xor(acc[r][q], off);
-        }
+        for (int r = 0; r < 4; ++r) { c1[r] += red[u][0][r][lane]; c2[r] += red[u][1][r][lane]; }
+    // lane (j, kq) holds T[row j][4 kq + r]; s1 of row j sits in lane (j, P / 4) register P % 4, s2 (the Gram diagonal) in lane (j, j / 4) register j % 4
+    float mean = 0.f, sd = 1.f;
+    if (ln) {
+        const float s1c = c1[P & 3];
+        const float s2c = (j & 3) == 0 ? c2[0] : (j & 3) == 1 ? c2[1] : (j & 3) == 2 ? c2[2] : c2[3];
+        const float s1 = __shfl(s1c, j + 16 * (P >> 2)), s2 = __shfl(s2c, j + 16 * (j >> 2));
+        mean = s1 / (float)K;
+        sd = sqrtf(fmaxf(s2 / (float)K - mean * mean, 0.f) + eps);            // 1 / rstd
     }
-    // lane l writes pad column l of every row: the row's own values at [set * P, set * P + P), zeros elsewhere
-    const int q_of_lane = lane - set * P;
+    if (m0 + j >= mend) return;
+    // this lane's 4 values go to pad columns set * P + 4 kq .. (when 4 kq < P); every other group of 4 pad columns of the row gets zeros
+    bf16_t* prow = A + (m0 + j) * lda + K;
+    uint2 v = make_uint2(0u, 0u);
+    if (4 * kq < P) {
+        float t[4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (m0 + r >= rows) break;
-        float mean = 0.f, sd = 1.f;
-        if (ln) {
-            mean = s1[r] / (float)K;
-            sd = sqrtf(fmaxf(s2[r] / (float)K - mean * mean, 0.f) + eps);          // 1 / rstd
+        for (int r = 0; r < 4; ++r) {
+            const int q = 4 * kq + r;
+            t[r] = ln ? c1[r] - mean * dcolsum[set * P + q] + dbias[set * P + q] * sd : c1[r];
         }
-        float x = 0.f;
+        v = make_uint2(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]));
+    }
+    // 16 groups of 4 columns per row, 4 lanes (kq) per row: lane kq writes groups kq, kq + 4, kq + 8, kq + 12 -- its own values at group
+    // (set * P) / 4 + kq' where kq' < P / 4 ... handled by value: group g holds values iff set * P / 4 <= g < (set * P + P) / 4
+    const int g0 = (set * P) >> 2;
 #pragma unroll
-        for (int q = 0; q < P; ++q)
-            if (q == q_of_lane) x = ln ? acc[r][q] - mean * dcolsum[set * P + q] + dbias[set * P + q] * sd : acc[r][q];
-        A[(m0 + r) * lda + K + lane] = f2bf(x);
+    for (int u = 0; u < 4; ++u) {
+        const int g = kq + 4 * u;                            // this lane writes group g; the values for it live in lane kq' = g - g0 of this row
+        const int src = g - g0;
+        const bool has = src >= 0 && 4 * src < P;
+        const unsigned vx = __shfl(v.x, j + 16 * (has ? src : 0)), vy = __shfl(v.y, j + 16 * (has ? src : 0));
+        *(uint2*)(prow + 4 * g) = has ? make_uint2(vx, vy) : make_uint2(0u, 0u);
     }
 }
 }  // namespace
@@ -667,16 +677,10 @@ extern "C" int tmix_lora_down(void* A, int64_t lda, int K, int64_t rows, const v
     if ((dcolsum == nullptr) != (dbias == nullptr)) TMIX_FAIL(TMIX_EINVAL, "lora_down: the folded-LayerNorm form needs dcolsum and dbias");
     if (!aligned16(A) || !aligned16(D)) TMIX_FAIL(TMIX_EALIGN, "lora_down: A / D must be 16-byte aligned");
     const int ln = dcolsum != nullptr;
-    if (rows_per_set <= 0) TMIX_FAIL(TMIX_ESHAPE, "lora_down: rows_per_set=%lld", (long long)rows_per_set);
-    // rows per wave: as many as divide a concept's row block (its rows share one set of down matrices)
-    const int R = (P == 4 && rows_per_set % 8 == 0) ? 8 : rows_per_set % 4 == 0 ? 4 : rows_per_set % 2 == 0 ? 2 : 1;
-    const int64_t waves = (rows + R - 1) / R;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
-    hipStream_t st = (hipStream_t)stream;
-#define TMIX_LORA_DOWN(PP, RR) lora_down_kernel<PP, RR><<<grid, 256, 0, st>>>((bf16_t*)A, lda, K, rows, (const bf16_t*)D, dcolsum, dbias, eps, ln, sets, rows_per_set)
-    if (P == 12) { if (R == 4) TMIX_LORA_DOWN(12, 4); else if (R == 2) TMIX_LORA_DOWN(12, 2); else TMIX_LORA_DOWN(12, 1); }
-    else { if (R == 8) TMIX_LORA_DOWN(4, 8); else if (R == 4) TMIX_LORA_DOWN(4, 4); else if (R == 2) TMIX_LORA_DOWN(4, 2); else TMIX_LORA_DOWN(4, 1); }
-#undef TMIX_LORA_DOWN
+    if (rows_per_set <= 0 || (rows % rows_per_set) || (K % 32)) TMIX_FAIL(TMIX_ESHAPE, "lora_down: rows=%lld must be a multiple of rows_per_set=%lld and K=%d of 32", (long long)rows, (long long)rows_per_set, K);
+    const unsigned grid = (unsigned)((rows / rows_per_set) * ((rows_per_set + 15) / 16));
+    if (P == 12) lora_down_kernel<12><<<grid, 256, 0, (hipStream_t)stream>>>((bf16_t*)A, lda, K, rows, (const bf16_t*)D, dcolsum, dbias, eps, ln, sets, rows_per_set);
+    else lora_down_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>((bf16_t*)A, lda, K, rows, (const bf16_t*)D, dcolsum, dbias, eps, ln, sets, rows_per_set);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
