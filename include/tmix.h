@@ -147,6 +147,13 @@ typedef struct {
     const float* ln_colsum; int64_t strideLnColsum;   /* fp32 [batch?][N] (stride 0: shared) */
     float ln_inv_c, ln_eps;                           /* 1/C and eps of the LayerNorm */
     int32_t ln_parts, reserved0;                      /* partials per row in ln_stats, 1..16 */
+    /* --- GroupNorm statistics from the launch that WRITES the normalised tensor (diffusers ResnetBlock2D.norm1/norm2,
+     * Transformer2DModel.norm, conv_norm_out read what a conv / proj_out / conv_shortcut launch has just stored): NULL, or fp32
+     * [M / TMIX_COLSTATS_ROWS][2][N]: plane 0 the sum, plane 1 the sum of squares of every column over rows [32 r, 32 r + 32) of
+     * the STORED (bf16-rounded) output.  Plain stores in a fixed order (nothing to zero, replays are bit-reproducible), the same
+     * layout under every tiling; tmix_groupnorm_nhwc_pre consumes it.  Plain bf16 epilogue only (no transposed region, no
+     * activation, no row_stats_out / e4m3 copy), batch == 1, M %% 32 == 0, N %% 8 == 0, 16-byte aligned C / residual rows. */
+    float* col_stats_out;
 } tmix_gemm_desc;
 int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
 /* Hint for the NEXT tmix_gemm_bf16 / tmix_conv3x3_nhwc launch issued by this host thread (consumed and cleared by it): while its
@@ -175,6 +182,7 @@ int tmix_gemm_prefetch_next(const void* next_weights, int64_t bytes, void* strea
  *                           that reads C as its A operand: Ct = bytes [batch*M][ldct] (ldct >= N), and the scale array [N/32][batch*M]
  *                           starts strideCt BYTES behind Ct.  M %% 32 == 0, N %% 32 == 0. */
 enum { TMIX_F8_A_BLOCK_SCALES = 1, TMIX_F8_GEGLU_OUT = 2, TMIX_F8_COPY_OUT = 4 };
+#define TMIX_COLSTATS_ROWS 32   /* rows per partial of col_stats_out */
 int tmix_gemm_fp8(const tmix_gemm_desc* d, const uint8_t* scale_a, const uint8_t* scale_w, void* stream);
 /* Row quantiser for tmix_gemm_fp8: X bf16 [rows][ld] -> Q e4m3 [rows][ldq] and scale_e8m0[r] = the smallest exponent that brings
  * max|X[r]| under 448 (K %% 8 == 0, K <= 8192).  Used on activations before each fp8 GEMM and once on the weights. */
@@ -204,6 +212,7 @@ typedef struct {
     int32_t tile_cfg;            /* TMIX_TILE_*                                */
     int32_t batch_bias_images;   /* consecutive images that share one batch_bias row (0/1: one row per image; the video
                                     UNet folds frames into B and has one time embedding per clip: = frames) */
+    float* col_stats_out;        /* NULL or fp32 [B*Ho*Wo / 32][2][Cout]: as in tmix_gemm_desc (B*Ho*Wo %% 32 == 0, Cout %% 8 == 0) */
 } tmix_conv_desc;
 int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
 
@@ -242,6 +251,15 @@ int tmix_groupnorm_ws_chunks(int64_t HW);   /* statistics workgroups per image (
 int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                         const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
                         void* stream);
+/* The same normalisation with the statistics pass replaced by the column partials the PRODUCERS of the tensor left behind
+ * (tmix_gemm_desc.col_stats_out / tmix_conv_desc.col_stats_out): cs1 = fp32 [B*HW / 32][2][cs1_channels] covers channels
+ * [0, cs1_channels), cs2 (NULL with cs2_channels = 0) the cs2_channels behind them; cs1_channels + cs2_channels = C1 + C2.  The split of
+ * the statistics need not be the split of X: the up-blocks normalise ONE concatenated tensor whose halves were written by two launches.
+ * HW %% 32 == 0.  Two launches (combine partials -> scale / shift per channel, apply) instead of three, and X is read once instead of
+ * twice.  Same ws as tmix_groupnorm_nhwc. */
+int tmix_groupnorm_nhwc_pre(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
+                            const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                            const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream);
 int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta, int64_t rows, int C,
                    float eps, void* stream);
 /* hipMemsetAsync(ptr, 0, nbytes) on the stream (graph-capturable): zeroes the LayerNorm statistics accumulators */

@@ -420,6 +420,100 @@ def test_groupnorm(ops, B, HW, C1, C2, silu):
     close(y, ref.transpose(1, 2))
 
 
+def _colstats_ref(out):
+    """[rows/32, 2, C]: column sums and sums of squares of the STORED bf16 values over each 32-row block (fp64 reference)"""
+    y = out.reshape(-1, out.shape[-1]).double()
+    blk = y.reshape(y.shape[0] // 32, 32, y.shape[1])
+    return torch.stack([blk.sum(1), (blk * blk).sum(1)], 1)
+
+
+def _colstats_close(cs, out):
+    ref = _colstats_ref(out)
+    assert cs.shape == ref.shape and torch.isfinite(cs).all()
+    err = (cs.double() - ref).abs()
+    tol = 1e-5 * ref.abs() + 1e-5 * ref[:, 1:].sqrt().max() + 1e-6          # fp32 sums of 32 values
+    assert (err <= tol).all(), f"max err {err.max().item():.4g} at {ref.abs().max().item():.4g}"
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("M,N,K,res", [(256, 320, 128, True), (1024, 1280, 64, True), (96, 200, 64, False), (4096, 640, 64, False)])
+def test_gemm_leaves_groupnorm_column_statistics(ops, cfg, M, N, K, res):
+    """col_stats_out: the producer-side GroupNorm statistics (straight-line and generic staged epilogues, every tiling, ragged tile edges)"""
+    a, w = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=K ** -0.5)
+    bias = rnd(N, seed=63, dtype=torch.float32)
+    r = rnd(M, N, seed=64) if res else None
+    cs = ops.colstats_buf(M, N, "cuda")
+    cs.fill_(float("nan"))                                     # every element is written
+    out = ops.gemm(a, w, bias=bias, residual=r, tile_cfg=cfg, col_stats_out=cs)
+    assert torch.equal(out, ops.gemm(a, w, bias=bias, residual=r, tile_cfg=cfg))       # C itself is untouched by the option
+    _colstats_close(cs, out)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 5, 7, 12, 13, 14, 15])
+@pytest.mark.parametrize("mode,B,H,W,Cin,Cout,res", [(0, 2, 16, 16, 64, 320, True), (1, 1, 16, 16, 128, 64, False), (2, 3, 8, 8, 64, 136, False),
+                                                      (0, 2, 32, 32, 64, 640, True)])
+def test_conv_leaves_groupnorm_column_statistics(ops, cfg, mode, B, H, W, Cin, Cout, res):
+    x = rnd(B, H, W, Cin, seed=65)
+    w = rnd(Cout, 3, 3, Cin, seed=66, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=67, dtype=torch.float32)
+    temb = rnd(B, Cout, seed=68, dtype=torch.float32)
+    Ho, Wo = ops.conv_out_hw(H, W, mode)
+    r = rnd(B, Ho, Wo, Cout, seed=69) if res else None
+    cs = ops.colstats_buf(B * Ho * Wo, Cout, "cuda")
+    cs.fill_(float("nan"))
+    out = ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=r, mode=mode, tile_cfg=cfg, col_stats_out=cs)
+    assert torch.equal(out, ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=r, mode=mode, tile_cfg=cfg))
+    _colstats_close(cs, out)
+
+
+def test_column_statistics_reject_what_they_cannot_serve(ops):
+    from tweediemix_amd import lib as L
+    a, w = rnd(128, 64), rnd(128, 64)
+    with pytest.raises(L.TmixError):                          # GEGLU epilogue
+        ops.gemm(a, w, geglu=True, col_stats_out=torch.empty(4, 2, 128, device="cuda"))
+    with pytest.raises(L.TmixError):                          # transposed region
+        ops.gemm(a, w, out_t=torch.empty(128, 128, device="cuda", dtype=BF), n_trans_begin=0, col_stats_out=torch.empty(4, 2, 128, device="cuda"))
+    with pytest.raises(L.TmixError):                          # HW not a multiple of 32
+        ops.groupnorm(rnd(1, 48, 64), rnd(64, dtype=torch.float32), rnd(64, dtype=torch.float32), colstats=(torch.empty(1, 2, 64, device="cuda"), None))
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (1, 1024, 1280, 0, False), (2, 64, 640, 320, True),
+                                             (1, 1024, 1280, 640, True), (4, 4096, 320, 0, True), (2, 32, 32, 0, False)])
+def test_groupnorm_from_producer_partials(ops, B, HW, C1, C2, silu):
+    """tmix_groupnorm_nhwc_pre: the statistics come from column partials (here: exact ones), incl. groups that straddle the two sources (1920 / 32 = 60)"""
+    x1 = rnd(B, HW, C1, seed=70) + 0.5
+    x2 = rnd(B, HW, C2, seed=71) * 2 if C2 else None
+    Cc = C1 + C2
+    g = rnd(Cc, seed=72, dtype=torch.float32)
+    b = rnd(Cc, seed=73, dtype=torch.float32)
+    cs1 = _colstats_ref(x1).float().contiguous()
+    cs2 = _colstats_ref(x2).float().contiguous() if C2 else None
+    y = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2, colstats=(cs1, cs2))
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], -1)
+    ref = F.group_norm(xin.transpose(1, 2), 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref.transpose(1, 2))
+    y0 = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2)       # the three-launch form: same values up to the summation order of the statistics
+    assert (y.float() - y0.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    if C2:                                                    # ONE concatenated tensor, statistics still in two pieces (the up-blocks' case): bit-equal
+        yc = ops.groupnorm(xin.to(BF).contiguous(), g, b, 32, 1e-5, silu, colstats=(cs1, cs2))
+        assert torch.equal(yc, y)
+
+
+def test_conv_groupnorm_chain_through_the_partials(ops):
+    """conv -> GroupNorm + SiLU as the UNet plan issues it: conv with col_stats_out, then tmix_groupnorm_nhwc_pre"""
+    B, H, W, Cin, Cout = 2, 32, 32, 64, 320
+    x = rnd(B, H, W, Cin, seed=75)
+    w = rnd(Cout, 3, 3, Cin, seed=76, scale=(9 * Cin) ** -0.5)
+    g, b = rnd(Cout, seed=77, dtype=torch.float32), rnd(Cout, seed=78, dtype=torch.float32)
+    cs = ops.colstats_buf(B * H * W, Cout, "cuda")
+    h = ops.conv3x3(x, w, col_stats_out=cs, tile_cfg=12).view(B, H * W, Cout)
+    y = ops.groupnorm(h, g, b, 32, 1e-5, True, colstats=(cs, None))
+    ref = F.silu(F.group_norm(h.float().transpose(1, 2), 32, g, b, 1e-5)).transpose(1, 2)
+    close(y, ref)
+
+
 @pytest.mark.parametrize("M", [4, 16, 37])
 def test_linear_small_sections_matches_separate_launches(ops, M):
     """tmix_linear_small_sections: stacked weight matrices sharing the input, each section leaving as its own dense [M, width]

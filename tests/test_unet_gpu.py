@@ -68,6 +68,29 @@ def test_unet_plan_matches_oracle(kind, B, routed, hw):
     assert torch.equal(eps, eps2)
 
 
+@pytest.mark.parametrize("kind,hw", [("lora", (32, 32)), ("custom", (16, 16))])
+def test_groupnorm_statistics_from_the_producers_match_the_statistics_kernel(kind, hw, monkeypatch):
+    """the default plan takes every GroupNorm's statistics from the conv / proj_out launch that wrote the tensor (col_stats_out ->
+    tmix_groupnorm_nhwc_pre; concatenations carry their two sources' partials); TMIX_GN_STATS_KERNEL=1 is the three-launch form.
+    Same network, same weights: the two differ only in the summation order of the statistics."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    h, w = hw
+    orc, plan, x, ehs, pooled, time_ids = make(kind, 4, h, w, True)
+    names = [fn.__name__ for fn, _a in plan.ops]
+    n_pre, n_old = names.count("tmix_groupnorm_nhwc_pre"), names.count("tmix_groupnorm_nhwc")
+    assert n_pre > 0 and (h % 32 or n_old <= 2), (n_pre, n_old)        # at 32 x 32 only conv_in's consumers keep the statistics kernel (level 2 is 8 x 8 = 64 pixels: fused too)
+    eps = plan(x.cuda(), 500).float().cpu()
+    monkeypatch.setenv("TMIX_GN_STATS_KERNEL", "1")
+    _orc, plan0, *_ = make(kind, 4, h, w, True)
+    assert "tmix_groupnorm_nhwc_pre" not in [fn.__name__ for fn, _a in plan0.ops]
+    eps0 = plan0(x.cuda(), 500).float().cpu()
+    ref = orc.forward(x, 500, ehs, pooled, time_ids, routed=True)
+    print(f"{kind} {hw}: {n_pre} norms from producer partials, {n_old} with their own statistics pass; fused vs three-launch rel_l2={rel_l2(eps, eps0):.3g}, "
+          f"vs oracle {rel_l2(eps, ref):.3g} / {rel_l2(eps0, ref):.3g}")
+    assert rel_l2(eps, ref) <= 2e-2 and rel_l2(eps, eps0) <= 1e-2
+
+
 @pytest.mark.parametrize("hw", [(16, 16), (8, 24)])
 def test_unet_plan_with_lora_in_low_rank_form_matches_oracle_and_the_merged_plan(hw):
     """UNetWeights(lora_mode="lowrank"): up(down(x)) as the routed projections' last K-tile (tmix_lora_down fills the pad columns,

@@ -50,6 +50,8 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         else if (cfg == 17) cfg = 2;
         else if (cfg >= 18) cfg = 12;
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
+    // column statistics (cs_out) are compiled for the lock-step tilings only: the phase-offset ones run as their nearest plain tiling
+    if (p.cs_out) { if (cfg == 16) cfg = 4; else if (cfg == 17) cfg = 2; }
     int rc = launch_group0(cfg, conv, f8, p, batch, st);
     if (rc == -999) rc = launch_group1(cfg, conv, f8, p, batch, st);
     if (rc == -999) rc = launch_group2(cfg, conv, f8, p, batch, st);
@@ -151,6 +153,13 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
         else if (c16 && r16 && (d->N % 8) == 0) p.wide |= 1;
         if (has_trans && aligned16(d->Ct) && (d->ldct % 8) == 0 && (d->strideCt % 8) == 0) p.wide |= 4;
     }
+    if (d->col_stats_out) {
+        if (has_trans || d->epilogue != TMIX_EPI_NONE || d->row_stats_out || (d->reserved0 & TMIX_F8_COPY_OUT) || d->batch != 1 || (d->M % TMIX_COLSTATS_ROWS) || (d->N % 8)
+            || !aligned16(d->col_stats_out) || !(p.wide & 1))
+            TMIX_FAIL(TMIX_EINVAL, "gemm: col_stats_out needs the plain staged bf16 epilogue (16-byte aligned C / residual rows, N %% 8 == 0), batch == 1, M %% 32 == 0, "
+                                   "and neither row_stats_out nor the e4m3 copy");
+        p.cs_out = d->col_stats_out;
+    }
     if (p.f8out && !(p.wide & 2)) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: e4m3 GEGLU output needs the staged epilogue");
     if (p.f8copy && !(p.wide & 1)) TMIX_FAIL(TMIX_EALIGN, "gemm: the e4m3 copy needs the staged epilogue (16-byte aligned C / residual rows, N %% 8 == 0)");
     if (fp8 && has_trans && !(p.wide & 4)) TMIX_FAIL(TMIX_EALIGN, "gemm_fp8: the transposed region needs a 16-byte aligned Ct with ldct %% 8 == 0");
@@ -193,5 +202,10 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
     p.bytesW = (unsigned)((int64_t)d->Cout * p.ntaps * d->Cin * 2);
     p.wide = (!getenv("TMIX_NARROW_EPILOGUE") && aligned16(d->Y) && (d->Cout % 8) == 0 && (!d->residual || aligned16(d->residual))) ? 1 : 0;
+    if (d->col_stats_out) {
+        if ((M % TMIX_COLSTATS_ROWS) || !aligned16(d->col_stats_out) || !p.wide)
+            TMIX_FAIL(TMIX_EINVAL, "conv3x3: col_stats_out needs B*Ho*Wo %% 32 == 0, Cout %% 8 == 0 and 16-byte aligned Y / residual");
+        p.cs_out = d->col_stats_out;
+    }
     return launch(1, p, 1, d->tile_cfg, (hipStream_t)stream);
 }

@@ -4,10 +4,10 @@
 namespace tmix_gemm {
 
 int launch_group2(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st) {
-    if (cfg == 7) return conv ? launch_cfg<128, 160, 4, 1, 2, 1>(p, batch, st) : launch_cfg<128, 160, 4, 1, 2, 0>(p, batch, st);
-    if (cfg == 12) return conv ? launch_cfg<128, 160, 4, 1, 4, 1>(p, batch, st) : launch_cfg<128, 160, 4, 1, 4, 0>(p, batch, st);
-    if (cfg == 13) return conv ? launch_cfg<64, 160, 1, 5, 4, 1>(p, batch, st) : launch_cfg<64, 160, 1, 5, 4, 0>(p, batch, st);
-    if (!conv && cfg == 18) return launch_cfg<128, 160, 4, 1, 4, 0, 0, 0, 2>(p, batch, st);     // tiling 12 + in-workgroup split-K
+    if (cfg == 7) return conv ? launch_cs<128, 160, 4, 1, 2, 1>(p, batch, st) : launch_cs<128, 160, 4, 1, 2, 0>(p, batch, st);
+    if (cfg == 12) return conv ? launch_cs<128, 160, 4, 1, 4, 1>(p, batch, st) : launch_cs<128, 160, 4, 1, 4, 0>(p, batch, st);
+    if (cfg == 13) return conv ? launch_cs<64, 160, 1, 5, 4, 1>(p, batch, st) : launch_cs<64, 160, 1, 5, 4, 0>(p, batch, st);
+    if (!conv && cfg == 18) return launch_cs<128, 160, 4, 1, 4, 0, 0, 0, 2>(p, batch, st);     // tiling 12 + in-workgroup split-K
     return -999;
 }
 

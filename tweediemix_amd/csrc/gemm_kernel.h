@@ -52,6 +52,21 @@ static __device__ __forceinline__ float quad_max(float x) {
     return fmaxf(x, y);
 }
 
+// DPP move within rows of 16 lanes (CTRL 0x120 + n: row_ror:n -- lane l reads lane (l - n) mod 16 of its row)
+template <int CTRL> static __device__ __forceinline__ float dpp_row(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// two reductions for the price of one: a summed over the lane pairs (l, l ^ 32) lands in lanes 0-31, b in lanes 32-63 ...
+static __device__ __forceinline__ float swap32_sum(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// ... and over (l, l ^ 16): a lands in the even rows of 16 lanes, b in the odd ones
+static __device__ __forceinline__ float swap16_sum(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct Params {
     const bf16_t* A; int64_t lda, strideA;
     const bf16_t* W; int64_t ldw, strideW;
@@ -75,6 +90,7 @@ struct Params {
     unsigned char* f8copy; int64_t ldF8copy;                    // plain epilogue: e4m3 COPY of the stored bf16 rows (+ scale_out [N/32][ldScaleOut])
     const char* pf; long long pf_bytes;                         // tmix_gemm_prefetch_next: the next launch's weights, touched in the prologue
     int pf_per;                                                 // 128-byte lines per touching thread (host-computed: a 64-bit division in every wave's prologue otherwise)
+    float* cs_out;                                              // GroupNorm producer side: fp32 [M/32][2][N] column {sums | sums of squares} per 32-row block
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -106,7 +122,11 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // and after the loop group 1 hands its partial tile to group 0 through the (now free) staging ring.  For this path's
 // one-tile-per-CU launches (4096 x 1280: 256 tiles of 128 x 160) the K loop is bound by how fast a CU can pull operands
 // L2 -> LDS, and that rate grows with the number of waves issuing DMA (measured 38 GB/s per CU with four, 52 with eight).
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
+// CS = 1: the instantiation that also leaves GroupNorm column statistics (Params::cs_out).  Its own kernel, not one more flavour inside the
+// common one: with the two extra epilogue bodies compiled into every kernel the launches that do NOT use them lost 0.3 ms per step (same-box
+// A/B, tools/jobs/r3zy_gn_fused.sh: GEMM class 19.21 -> 19.40 ms; the register allocation of the 256 x 320 tiling moved) -- as much as the
+// statistics kernels they replace cost.  The CS = 0 kernels are the code they were before.
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0>
 // (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
 __global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? (NS * (BM + BN) * 128 > 80 * 1024 ? 2 : 3) : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
@@ -1045,19 +1065,50 @@ gemm_conv_kernel(const Params p) {
             for (int q = 0; q < 4; ++q) { sa1[i][q] = 0.f; sa2[i][q] = 0.f; }
             sb1[i][0] = sb1[i][1] = sb2[i][0] = sb2[i][1] = 0.f;
         }
-        // FL > 0: the STRAIGHT-LINE form for the common case (bf16 output, no activation; FL bit 1 also keeps the row statistics, bit 2
+        // FL bit 0: the STRAIGHT-LINE form for the common case (bf16 output, no activation; FL bit 1 also keeps the row statistics, bit 2
         // also leaves the e4m3 copy of the stored rows).  With one wave per SIMD the epilogue is bound by VALU issue and by the latencies nobody hides
         // (tools/jobs/r3za_epi_abl.sh: 5.3 of its 6.7 us on 128 x 160 tiles remain with bias loads, residual and stores all removed), and the
         // generic form below has a dozen wave-uniform branches per pass, each a scheduling barrier and a fetch bubble.  Here bias and
         // residual come from registers filled in front of the last K-tile (zeros when the launch has none: x * 1 + 0 and x + 0 leave
         // every value as it was), a lane outside the tile is handled by predicating its store, and the passes of a chunk interleave.
+        // GroupNorm producer side (cs_out; flavour bit 8): column sums and sums of squares of the values AS STORED, per 32-row block -- the
+        // granularity at which a wave owns whole columns in every tiling, so there is no exchange between waves, no barrier, and the buffer
+        // layout [M / 32][2][N] does not depend on the tiling.  A lane of the staged epilogue holds 8 columns of one row per pass: it adds
+        // its rows up in cv (sums in 0-7, squares in 8-15), then the 8 (16) lanes that share its columns are reduced as a reduce-SCATTER:
+        // every permlane swap settles two values at once (one ends in each half), so 16 values cost 8 + 4 swaps and 4 (8) DPP adds, and
+        // lane (bit 5 = statistic, bit 4 = column half) ends with four adjacent columns of one plane: one 16-byte store.
+        auto cs_flush = [&](float (&cv)[16], int mb, int nc, bool ncok, auto cf_tag) __attribute__((always_inline)) {
+            constexpr int CF = decltype(cf_tag)::value;
+            float t[8], u[4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = swap32_sum(cv[k], cv[8 + k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = swap16_sum(t[k], t[k + 4]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] += dpp_row<0x128>(u[k]);
+            if constexpr (CF == 1) {                                 // 4 lanes per row: the lanes of a column also differ in bit 2
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[k] += dpp_row<0x124>(u[k]);
+            }
+            if (!(lane & (CF == 1 ? 12 : 8)) && mb < p.M && ncok)
+                *(float4*)(p.cs_out + ((int64_t)(mb >> 5) * 2 + (lane >> 5)) * p.N + nc + ((lane >> 4) & 1) * 4) = make_float4(u[0], u[1], u[2], u[3]);
+        };
+        auto cs_add = [&](float (&cv)[16], const uint4& v) __attribute__((always_inline)) {
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(u[k] << 16), hi = __uint_as_float(u[k] & 0xffff0000u);
+                cv[2 * k] += lo; cv[2 * k + 1] += hi;
+                cv[8 + 2 * k] = fmaf(lo, lo, cv[8 + 2 * k]); cv[9 + 2 * k] = fmaf(hi, hi, cv[9 + 2 * k]);
+            }
+        };
         auto chunk = [&](int j0, auto cf_tag, auto fl_tag) __attribute__((always_inline)) {     // CF fragments = CF * 32 fp32 columns of every 32-row block
             constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, SR = CW * 4 + 16, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
             constexpr int FL = decltype(fl_tag)::value;              // (tilings without the residual registers: launches without residual only)
             const int rr = lane / LPR, cc = (lane % LPR) * 8;
             const int nc = n0 + wc * TN + j0 * 32 + cc;
             const bool ncok = nc < p.N;
-            if constexpr (FL > 0) {
+            if constexpr ((FL & 1) != 0) {
                 constexpr int CI = CF == 2 ? 0 : (FN / 2) * 4;          // residual pieces of this chunk inside rw (plus (j0 / 2) * 4 for pairs)
                 const bool lnf = p.ln_stats != nullptr;
                 const float4 bq0 = *(const float4*)(bias_lds + wc * TN + j0 * 32 + cc), bq1 = *(const float4*)(bias_lds + wc * TN + j0 * 32 + cc + 4);
@@ -1070,6 +1121,11 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int mb = m0 + wr * TM + i * 32;
+                    float cv[(FL & 8) ? 16 : 1];
+                    if constexpr ((FL & 8) != 0) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) cv[k] = 0.f;
+                    }
 #pragma unroll
                     for (int jj = 0; jj < CF; ++jj)
 #pragma unroll
@@ -1126,7 +1182,9 @@ gemm_conv_kernel(const Params p) {
                             if (!ok) { a1 = 0.f; a2 = 0.f; }
                             if constexpr (CF == 2) { sa1[i][ps] += a1; sa2[i][ps] += a2; } else { sb1[i][ps] += a1; sb2[i][ps] += a2; }
                         }
+                        if constexpr ((FL & 8) != 0) cs_add(cv, v);     // (M % 32 == 0: a 32-row block is inside the matrix or not stored at all)
                     }
+                    if constexpr ((FL & 8) != 0) cs_flush(cv, mb, nc, ncok, cf_tag);
                 }
                 return;
             }
@@ -1140,6 +1198,11 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int mb = m0 + wr * TM + i * 32;
+                float cv[(FL & 8) ? 16 : 1];
+                if constexpr ((FL & 8) != 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) cv[k] = 0.f;
+                }
                 uint4 rv[NP];
                 if (Rb && !(ABL & 64)) {
 #pragma unroll
@@ -1219,8 +1282,10 @@ gemm_conv_kernel(const Params p) {
                             }
                             if constexpr (CF == 2) { sa1[i][ps] += a1; sa2[i][ps] += a2; } else { sb1[i][ps] += a1; sb2[i][ps] += a2; }
                         }
+                        if constexpr ((FL & 8) != 0) cs_add(cv, v);
                     }
                 }
+                if constexpr ((FL & 8) != 0) cs_flush(cv, mb, nc, ncok, cf_tag);
             }
         };
         // chunks of two fragments (64 columns: 8 lanes x 16 bytes per row), a last single one when FN is odd
@@ -1233,8 +1298,10 @@ gemm_conv_kernel(const Params p) {
         const bool fastp = (WPREF || !Rb) && !f32out && p.epilogue == TMIX_EPI_NONE && (!p.rgb || (CONV && rgb_one)) && !(ABL & 0xf0);      // (ablation bit 7: the generic form only)
         bool f8q = false;
         if constexpr (F8C) f8q = p.f8copy != nullptr;
-        // flavour bits: 1 straight-line, 2 row statistics, 4 e4m3 copy
-        if (!fastp) chunks(std::integral_constant<int, 0>{});
+        // flavour bits: 1 straight-line, 2 row statistics, 4 e4m3 copy, 8 column statistics
+        // (8: column statistics for a GroupNorm behind this launch -- never together with row statistics or the e4m3 copy, gemm_conv.hip)
+        if constexpr (CS) { if (!fastp) chunks(std::integral_constant<int, 8>{}); else chunks(std::integral_constant<int, 9>{}); }
+        else if (!fastp) chunks(std::integral_constant<int, 0>{});
         else if (!f8q) { if (!sto) chunks(std::integral_constant<int, 1>{}); else chunks(std::integral_constant<int, 3>{}); }
         else { if constexpr (F8C) { if (!sto) chunks(std::integral_constant<int, 5>{}); else chunks(std::integral_constant<int, 7>{}); } }
         if (sto) {
@@ -1368,14 +1435,14 @@ struct TileCfg { int bm, bn; };
 // every SIMD hosts one math wave and one loader, and a K-tile's 36 LDS-DMA instructions are nine per loader
 constexpr int NUM_CFG = 21;
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
     constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4 + (CONV ? BN * 4 : 0)      // staging ring + fused-LayerNorm block + the tile's bias (+ time-embedding row)
                        + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
-    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS>;
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS, CS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1394,6 +1461,12 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     return TMIX_OK;
 }
 
+
+// the same tiling with or without the column statistics of Params::cs_out (its own instantiation, see gemm_conv_kernel)
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
+int launch_cs(Params& p, int batch, hipStream_t st) {
+    return p.cs_out ? launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1>(p, batch, st) : launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0>(p, batch, st);
+}
 
 // one launcher per group of tilings (defined in gemm_inst_<g>.hip); returns -999 when `cfg` is not in the group
 int launch_group0(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);

@@ -125,6 +125,66 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict
     }
 }
 
+// the same from the column partials the tensor's PRODUCERS wrote (tmix_gemm_desc.col_stats_out: [B*HW/32][2][Cs] per source): one
+// workgroup of 16 waves per (group, image) adds the group's channels over the image's 32-row blocks -- thread (j, c) walks blocks j, j + J, ...
+// of channel c (a fixed order; up to 512 blocks x 80 channels x 2 planes at the 128 x 128 level, where four waves were latency-bound:
+// 80 us for the whole norm against 67 with the statistics kernel) in fp32, threads combine in fp64 -- and folds gamma / beta.
+// No pass over X: the statistics launch of the three is gone.
+constexpr int GN_CS_T = 1024;
+__device__ __forceinline__ void gn_cs_walk(const float* __restrict__ base, int Cs, int n, int nblk, int tid, float& s, float& q) {
+    if (n <= 0) return;
+    const int J = GN_CS_T / n, j = tid / n, c = tid - j * n;       // J >= 4: n <= 256
+    if (j >= J) return;
+    const float* row = base + (int64_t)j * 2 * Cs + c;
+    const int64_t step = (int64_t)J * 2 * Cs;
+    int blk = j;
+    for (; blk + 3 * J < nblk; blk += 4 * J, row += 4 * step) {     // four blocks in flight per thread
+        const float a0 = row[0], b0 = row[Cs], a1 = row[step], b1 = row[step + Cs];
+        const float a2 = row[2 * step], b2 = row[2 * step + Cs], a3 = row[3 * step], b3 = row[3 * step + Cs];
+        s += (a0 + a1) + (a2 + a3); q += (b0 + b1) + (b2 + b3);
+    }
+    for (; blk < nblk; blk += J, row += step) { s += row[0]; q += row[Cs]; }
+}
+__global__ void __launch_bounds__(GN_CS_T) gn_finalize_cs_kernel(const float* __restrict__ cs1, int C1, const float* __restrict__ cs2, int C2,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float2* __restrict__ ss, int64_t HW, int groups, float eps,
+                                                                 unsigned long long* prof) {
+    __shared__ double s_red[2 * GN_CS_T / 64];
+    __shared__ float s_ms[2];
+    if (prof && threadIdx.x == 0) prof_enter(prof, (blockIdx.x | blockIdx.y) == 0, 0);
+    const int C = C1 + C2, cpg = C / groups;
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int nblk = (int)(HW / 32);
+    // gamma / beta of the channel this thread will write: requested before the reduction, whose result they do not depend on
+    float gm = 0.f, bt = 0.f;
+    if (tid < cpg) { gm = gamma[g * cpg + tid]; bt = beta[g * cpg + tid]; }
+    // the group's channels that live in source 1 / source 2 (a group may straddle the two)
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int n1 = min(c_hi, C1) - min(c_lo, C1), n2 = cpg - n1;
+    float s = 0.f, q = 0.f;
+    gn_cs_walk(cs1 + (int64_t)b * nblk * 2 * C1 + c_lo, C1, n1, nblk, tid, s, q);
+    if (n2 > 0) gn_cs_walk(cs2 + (int64_t)b * nblk * 2 * C2 + (max(c_lo, C1) - C1), C2, n2, nblk, tid, s, q);
+    double sd = (double)s, qd = (double)q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sd += __shfl_xor(sd, o); qd += __shfl_xor(qd, o); }
+    if ((tid & 63) == 0) { s_red[(tid >> 6) * 2] = sd; s_red[(tid >> 6) * 2 + 1] = qd; }
+    __syncthreads();
+    if (tid == 0) {
+        double st = 0.0, qt = 0.0;
+#pragma unroll
+        for (int w = 0; w < GN_CS_T / 64; ++w) { st += s_red[2 * w]; qt += s_red[2 * w + 1]; }
+        const double n = (double)HW * cpg;
+        const double mean = st / n;
+        double var = qt / n - mean * mean; if (var < 0.0) var = 0.0;
+        s_ms[0] = (float)mean; s_ms[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (tid < cpg) {
+        const float sc = s_ms[1] * gm;
+        ss[(int64_t)b * C + c_lo + tid] = make_float2(sc, bt - s_ms[0] * sc);
+    }
+}
+
 __device__ __forceinline__ float silu_fast(float x) {     // x * sigmoid(x) with v_exp_f32 / v_rcp_f32
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -487,6 +547,29 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     // ws layout: [B*chunks*groups*2] partial sums | [B*C] float2 scale/shift
     float2* ss = (float2*)(ws + (int64_t)B * GN_T * groups * 2);
     gn_finalize_kernel<<<dim3(groups, B), 64, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
+    TMIX_LAUNCH_CHECK();
+    int64_t nb = (HW * (C / 8) + GN_APPLY_ITEMS - 1) / GN_APPLY_ITEMS; if (nb < 1) nb = 1; if (nb > GN_APPLY_MAXB) nb = GN_APPLY_MAXB;
+    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);
+    TMIX_LAUNCH_CHECK();
+    return TMIX_OK;
+}
+
+extern "C" int tmix_groupnorm_nhwc_pre(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
+                                       const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                                       const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream) {
+    if (!X1 || !Y || !gamma || !beta || !ws || !cs1) TMIX_FAIL(TMIX_EINVAL, "groupnorm_pre: null pointer");
+    if (C2 > 0 && !X2) TMIX_FAIL(TMIX_EINVAL, "groupnorm_pre: C2 > 0 but X2 is null");
+    const int C = C1 + C2;
+    if (cs1_channels <= 0 || cs2_channels < 0 || cs1_channels + cs2_channels != C || (cs2_channels > 0 && !cs2))
+        TMIX_FAIL(TMIX_EINVAL, "groupnorm_pre: the partials cover %d + %d channels, the tensor has %d", cs1_channels, cs2_channels, C);
+    if (B <= 0 || HW <= 0 || C <= 0) TMIX_FAIL(TMIX_ESHAPE, "groupnorm_pre: empty problem");
+    if ((C1 % 8) || (C2 % 8) || C > GN_MAX_C || groups <= 0 || groups > 64 || (C % groups) || C / groups > 256) TMIX_FAIL(TMIX_ESHAPE, "groupnorm_pre: C1=%d C2=%d groups=%d unsupported", C1, C2, groups);
+    if (HW % TMIX_COLSTATS_ROWS) TMIX_FAIL(TMIX_ESHAPE, "groupnorm_pre: HW=%lld must be a multiple of %d (the producers' partials cover 32-row blocks)", (long long)HW, TMIX_COLSTATS_ROWS);
+    if (!aligned16(X1) || (X2 && !aligned16(X2)) || !aligned16(Y)) TMIX_FAIL(TMIX_EALIGN, "groupnorm_pre: pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* prof = tmix_prof_take();
+    float2* ss = (float2*)(ws + (int64_t)B * GN_T * groups * 2);           // the same workspace layout as tmix_groupnorm_nhwc
+    gn_finalize_cs_kernel<<<dim3(groups, B), GN_CS_T, 0, st>>>(cs1, cs1_channels, cs2, cs2_channels, gamma, beta, ss, HW, groups, eps, prof);
     TMIX_LAUNCH_CHECK();
     int64_t nb = (HW * (C / 8) + GN_APPLY_ITEMS - 1) / GN_APPLY_ITEMS; if (nb < 1) nb = 1; if (nb > GN_APPLY_MAXB) nb = GN_APPLY_MAXB;
     gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);

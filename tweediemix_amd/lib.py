@@ -44,14 +44,15 @@ class GemmDesc(C.Structure):
                 ("row_stats_out", vp), ("strideStatsOut", i64), ("ldStatsOut", i64),
                 ("ln_stats", vp), ("strideLnStats", i64), ("ldLnStats", i64),
                 ("ln_colsum", vp), ("strideLnColsum", i64), ("ln_inv_c", f32), ("ln_eps", f32),
-                ("ln_parts", C.c_int32), ("reserved0", C.c_int32)]
+                ("ln_parts", C.c_int32), ("reserved0", C.c_int32),
+                ("col_stats_out", vp)]
 
 
 class ConvDesc(C.Structure):
     """mirror of tmix_conv_desc"""
     _fields_ = [("X", vp), ("Wt", vp), ("Y", vp), ("bias", vp), ("batch_bias", vp), ("residual", vp),
                 ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("mode", i32), ("tile_cfg", i32),
-                ("batch_bias_images", i32)]
+                ("batch_bias_images", i32), ("col_stats_out", vp)]
 
 
 SIGNATURES = {
@@ -83,6 +84,8 @@ SIGNATURES = {
     "tmix_groupnorm_ws_floats": (i64, [C.c_int, C.c_int, C.c_int]),
     "tmix_groupnorm_nhwc": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, C.c_int, f32,
                                       C.c_int, vp]),
+    "tmix_groupnorm_nhwc_pre": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, C.c_int, f32,
+                                          C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "tmix_layernorm": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, f32, vp]),
     "tmix_zero": (C.c_int, [vp, i64, vp]),
     "tmix_temporal_attn": (C.c_int, [vp, i64, vp, i64, C.c_int, C.c_int, i64, C.c_int, f32, vp]),

@@ -70,7 +70,7 @@ def stats_parts(N, tile_cfg):
 
 def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows_per_group=0, geglu=False,
                    out_t=None, n_trans_begin=-1, tile_cfg=0, row_stats_out=None, ln_stats=None, ln_colsum=None,
-                   ln_eps=1e-5, ln_parts=0, act=None, out_f32=None, ln_k=None):
+                   ln_eps=1e-5, ln_parts=0, act=None, out_f32=None, ln_k=None, col_stats_out=None):
     """a [batch?,M,K] bf16 (last dim contiguous), w [batch?,N,K] bf16, out [batch?,M,N'] bf16."""
     a3 = a if a.dim() == 3 else a.unsqueeze(0)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -123,7 +123,24 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
         d.ln_parts = int(ln_parts) if ln_parts else st.shape[0]
         d.ln_colsum, d.strideLnColsum = ln_colsum.data_ptr(), (N if ln_colsum.dim() == 2 and batch > 1 else 0)
         d.ln_inv_c, d.ln_eps = 1.0 / (ln_k or K), ln_eps       # ln_k: the LayerNorm's width when A carries extra columns behind it (low-rank LoRA pad)
+    if col_stats_out is not None:          # GroupNorm partials of the stored rows: fp32 [M/32, 2, N] (colstats_buf)
+        cs = col_stats_out
+        assert batch == 1 and cs.dtype == torch.float32 and cs.is_contiguous() and tuple(cs.shape) == (M // COLSTATS_ROWS, 2, N) and M % COLSTATS_ROWS == 0
+        d.col_stats_out = cs.data_ptr()
     return d
+
+
+COLSTATS_ROWS = 32          # TMIX_COLSTATS_ROWS
+# largest image (pixels) whose GroupNorms take their statistics from the producers: the combine launch walks HW / 32 partials per channel, and beyond
+# 128 x 128 that pass loses to the statistics kernel's pass over x itself (VAE decode at 1024^2, all levels on the partials: 15.4 vs 14.7 ms)
+COLSTATS_MAX_HW = 16384
+
+
+def colstats_buf(rows, C, device):
+    """receiver of tmix_gemm_desc.col_stats_out / tmix_conv_desc.col_stats_out for an output of `rows` x C: fp32 [rows/32, 2, C],
+    plane 0 = column sums, plane 1 = column sums of squares over each 32-row block of the stored bf16 values."""
+    assert rows % COLSTATS_ROWS == 0 and C % 8 == 0
+    return torch.empty(rows // COLSTATS_ROWS, 2, C, device=device, dtype=torch.float32)
 
 
 class F8Copy:
@@ -220,7 +237,7 @@ def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, f8_cop
     return out if out is not None else kw.get("out_f32")
 
 
-def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0, bias_images=1):
+def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0, bias_images=1, col_stats_out=None):
     """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous ([Cout,3,Cin] for the temporal CONV_T3,
     where x is [clips, frames, h*w, Cin])."""
     B, H, W, Cin = x.shape
@@ -233,6 +250,10 @@ def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.
     d.B, d.H, d.W, d.Cin, d.Cout, d.mode = B, H, W, Cin, Cout, mode
     d.tile_cfg = tile_cfg
     d.batch_bias_images = bias_images      # consecutive images sharing one batch_bias row (video: frames of a clip)
+    if col_stats_out is not None:
+        cs = col_stats_out
+        assert cs.dtype == torch.float32 and cs.is_contiguous() and tuple(cs.shape) == (out.numel() // Cout // COLSTATS_ROWS, 2, Cout)
+        d.col_stats_out = cs.data_ptr()
     return d
 
 
@@ -240,14 +261,14 @@ def conv_out_hw(H, W, mode):
     return (H // 2, W // 2) if mode in (L.CONV_S2, L.CONV_S2A) else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
 
 
-def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0):
+def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0, col_stats_out=None):
     _need_cuda(x, w)
     lib = L.load()
     B, H, W, _ = x.shape
     Ho, Wo = conv_out_hw(H, W, mode)
     if out is None:
         out = torch.empty(B, Ho, Wo, w.shape[0], device=x.device, dtype=BF16)
-    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode, tile_cfg)
+    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode, tile_cfg, col_stats_out=col_stats_out)
     L.check(lib.tmix_conv3x3_nhwc(C.byref(d), _stream()), "tmix_conv3x3_nhwc")
     return out
 
@@ -297,8 +318,10 @@ def groupnorm_ws(B, C, groups, device):
     return torch.empty(L.load().tmix_groupnorm_ws_floats(B, C, groups), device=device, dtype=torch.float32)
 
 
-def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=None, ws=None):
-    """x1 [B,HW,C1] (+ optional x2 [B,HW,C2], normalised as channel-concat) bf16 NHWC."""
+def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=None, ws=None, colstats=None):
+    """x1 [B,HW,C1] (+ optional x2 [B,HW,C2], normalised as channel-concat) bf16 NHWC.
+    colstats: (cs1, cs2 or None) -- the column partials the tensor's producers left (colstats_buf; their channel counts add up to C1 + C2 but
+    need not be C1 and C2): tmix_groupnorm_nhwc_pre, no statistics pass."""
     _need_cuda(x1, gamma, beta)
     lib = L.load()
     B, HW, C1 = x1.shape[0], x1.numel() // (x1.shape[0] * x1.shape[-1]), x1.shape[-1]
@@ -308,6 +331,15 @@ def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=Non
         out = torch.empty(*x1.shape[:-1], C1 + C2, device=x1.device, dtype=BF16)
     if ws is None:
         ws = groupnorm_ws(B, C1 + C2, groups, x1.device)
+    if colstats is not None:
+        cs1, cs2 = colstats
+        ca, cb = cs1.shape[-1], (0 if cs2 is None else cs2.shape[-1])
+        assert cs1.is_contiguous() and cs1.shape[1] == 2 and (cs2 is None or (cs2.is_contiguous() and cs2.shape[:2] == cs1.shape[:2]))
+        if HW % COLSTATS_ROWS == 0:
+            assert cs1.shape[0] == B * HW // COLSTATS_ROWS
+        L.check(lib.tmix_groupnorm_nhwc_pre(_p(x1), C1, _p(x2), C2, _p(out), _p(gamma), _p(beta), _p(ws), B, HW, groups,
+                                            float(eps), int(bool(silu)), _p(cs1), ca, _p(cs2), cb, _stream()), "tmix_groupnorm_nhwc_pre")
+        return out
     L.check(lib.tmix_groupnorm_nhwc(_p(x1), C1, _p(x2), C2, _p(out), _p(gamma), _p(beta), _p(ws), B, HW, groups,
                                     float(eps), int(bool(silu)), _stream()), "tmix_groupnorm_nhwc")
     return out

@@ -322,6 +322,9 @@ class _Arena:
         for tns in ts:
             buf = tns._arena_buf
             self.free.setdefault(buf.numel(), []).append(buf)
+            for cs, _c in getattr(tns, "_cs", None) or ():  # GroupNorm column partials of this tensor (UNetPlan._colstats): every reader came before
+                self.put(cs)
+            tns._cs = None
 
 
 _TUNE_CACHE = {}      # repr((kind, shape key)) -> best TMIX_TILE_* id, shared by every plan in the process
@@ -430,6 +433,9 @@ class UNetPlan:
         # when that launch is planned): the chain otherwise meets every weight cold from HBM (TMIX_NO_PREFETCH=1 switches it off)
         self._pf_prev = None
         self._pf_on = not os.environ.get("TMIX_NO_PREFETCH")
+        # GroupNorm statistics come from the launch that WRITES the normalised tensor (col_stats_out of the conv / proj_out epilogue), so a
+        # norm is two launches (combine partials, apply) and one pass over x instead of three and two (TMIX_GN_STATS_KERNEL=1: the old form)
+        self._gn_fused = not os.environ.get("TMIX_GN_STATS_KERNEL")
         self._tunable = []                  # (index into self.ops, kind, descriptor) of every GEMM / conv launch
         self._ln_links = []                 # (producer desc, [consumer descs]): ln_parts follows the producer's tiling
         self._build()
@@ -515,11 +521,27 @@ class UNetPlan:
         self.keep.append(w)
         self.ops.append((self.lib.tmix_gemm_prefetch_next, self._pf_prev))
 
+    def _colstats(self, owner, rows, HW, Cc):
+        """column-partials buffer [rows/32, 2, Cc] for the launch that writes `owner` ([B, HW, Cc]); it travels with the tensor (owner._cs, released
+        with it) and _gn picks it up.  None when the geometry does not allow it (32-row blocks must not straddle images)."""
+        if not getattr(self, "_gn_fused", False) or HW % ops.COLSTATS_ROWS or HW > ops.COLSTATS_MAX_HW or rows % ops.COLSTATS_ROWS or Cc % 8:
+            return None
+        cs = self.arena.get(rows // ops.COLSTATS_ROWS, 2, Cc, dtype=F32)
+        owner._cs = ((cs, Cc),)
+        return cs
+
     def _gn(self, x, Cc, HW, name, eps, silu, out=None):
         out = out if out is not None else self.arena.get(self.B, HW, Cc)
         W = self.W
-        self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
-                   W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu))
+        parts = getattr(x, "_cs", None)
+        if parts and sum(c for _t, c in parts) == Cc:
+            (cs1, c1), (cs2, c2) = (parts[0], parts[1]) if len(parts) == 2 else (parts[0], (None, 0))
+            self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+                       W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu),
+                       cs1.data_ptr(), c1, cs2.data_ptr() if cs2 is not None else None, c2)
+        else:
+            self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+                       W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu))
         self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", self.B, HW, Cc))
         return out
 
@@ -532,6 +554,9 @@ class UNetPlan:
             return self._gemm_fp8(a, fp8_key, out, f8_copy=f8_copy, **kw)
         if kw.get("row_stats_out") is not None:
             kw.setdefault("tile_cfg", 1)            # the partial count depends on the tiling: never TMIX_TILE_AUTO
+        cs_owner = kw.pop("cs_owner", None)         # the [B, HW, N] tensor `out` is a view of: a GroupNorm reads it next
+        if cs_owner is not None and out.dim() == 2:
+            kw["col_stats_out"] = self._colstats(cs_owner, out.shape[0], cs_owner.shape[1], out.shape[1])
         d = ops.make_gemm_desc(a, w, out, **kw)
         if f8_copy is not None:
             f8_copy.attach(d)
@@ -604,7 +629,8 @@ class UNetPlan:
         Ho, Wo = ops.conv_out_hw(Hh, Ww, mode)
         out = self.arena.get(self.B, Ho * Wo, Cout)
         d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Cin), self.W[wname + ".weight"], out.view(self.B, Ho, Wo, Cout),
-                               self.W[wname + ".bias"], batch_bias, residual, mode, bias_images=bias_images)
+                               self.W[wname + ".bias"], batch_bias, residual, mode, bias_images=bias_images,
+                               col_stats_out=self._colstats(out, self.B * Ho * Wo, Ho * Wo, Cout))      # every conv output of this network feeds a GroupNorm
         self.keep.append(d)
         self._hint_weights(self.W[wname + ".weight"])
         self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
@@ -777,7 +803,7 @@ class UNetPlan:
             A.put(f)
         out = A.get(B, S, Cc)
         self._gemm(h.view(B * S, Cc), W[name + ".proj_out.weight"], out.view(B * S, Cc), bias=W[name + ".proj_out.bias"],
-                   residual=x.view(B * S, Cc))
+                   residual=x.view(B * S, Cc), cs_owner=out)
         A.put(h_full)
         if h8 is not None:
             A.put(h8buf)
@@ -786,6 +812,11 @@ class UNetPlan:
     def _cat(self, x1, C1, x2, C2, HW):
         out = self.arena.get(self.B, HW, C1 + C2)
         self._emit(self.lib.tmix_concat_channels, x1.data_ptr(), C1, x2.data_ptr(), C2, out.data_ptr(), self.B * HW)
+        # the concatenation's column partials are those of its two sources: they move to it (and are released with it, not with x1 / x2)
+        p1, p2 = getattr(x1, "_cs", None), getattr(x2, "_cs", None)
+        if getattr(self, "_gn_fused", False) and p1 and p2 and len(p1) == 1 and len(p2) == 1:
+            out._cs = (p1[0], p2[0])
+            x1._cs = x2._cs = None
         return out
 
     # ------------------------------------------------------------------ whole network
