@@ -126,7 +126,11 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // common one: with the two extra epilogue bodies compiled into every kernel the launches that do NOT use them lost 0.3 ms per step (same-box
 // A/B, tools/jobs/r3zy_gn_fused.sh: GEMM class 19.21 -> 19.40 ms; the register allocation of the 256 x 320 tiling moved) -- as much as the
 // statistics kernels they replace cost.  The CS = 0 kernels are the code they were before.
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0>
+// EK: the epilogue family compiled into the instantiation -- 0: all of them (transposed regions, the narrow forms, everything below), 1: the staged GEGLU
+// epilogue only, 2: the staged plain epilogue only (all its flavours), 3: the staged plain and the staged transposed form (q | k | V^T).  One kernel that can do everything carries every path's register demand: the
+// 256 x 320 tiling compiled with all families spills 35 VGPRs (144 bytes of scratch per lane, 179 KB of code), with the GEGLU family alone none
+// (227 VGPRs, 41 KB).  launch_cs picks the family from the launch's parameters; results are bit-identical (the same code, less of it).
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0>
 // (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
 __global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? (NS * (BM + BN) * 128 > 80 * 1024 ? 2 : 3) : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
@@ -445,7 +449,7 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool trans = (p.n_trans_begin >= 0) && (n0 >= p.n_trans_begin);
+    const bool trans = (EK == 1 || EK == 2) ? false : (p.n_trans_begin >= 0) && (n0 >= p.n_trans_begin);
     // transposed tiles: square wave tiles swap the two LDS sources in the main loop (the lane then owns 4 consecutive m of one
     // n); every other tiling accumulates as usual and transposes while staging the stores through LDS
     constexpr bool SQ = (FM == FN && TM == TN) && !PH;
@@ -461,7 +465,7 @@ gemm_conv_kernel(const Params p) {
     const int off_a = tswap ? offW : offA, off_b = tswap ? offA : offW;
     // residual rows are requested just before the last K-tile's MFMAs so their latency hides behind compute
     const bf16_t* Rb = p.R ? p.R + (int64_t)bz * p.strideR : nullptr;
-    const bool plain_epi = !trans && p.epilogue != TMIX_EPI_GEGLU && !(p.wide & 1);
+    const bool plain_epi = EK ? false : !trans && p.epilogue != TMIX_EPI_GEGLU && !(p.wide & 1);      // (the narrow plain form)
     constexpr bool PREF = FM * FN <= 4;               // large wave tiles have no registers to spare for it
     uint2 rres[PREF ? FM : 1][PREF ? FN : 1][4];
     auto prefetch_residual = [&]() {
@@ -485,7 +489,7 @@ gemm_conv_kernel(const Params p) {
     constexpr int WP_I = (FN / 2) * 4 + (FN & 1) * 2;          // 16-byte residual pieces per lane per 32-row block
     constexpr bool WPREF = FM * WP_I <= 12;
     uint4 rw[WPREF ? FM * WP_I : 1];
-    const bool wide_res = WPREF && Rb && (p.wide & 1) && kg == 0 && !(ABL & 64);
+    const bool wide_res = EK != 1 && WPREF && Rb && (EK >= 2 || (p.wide & 1)) && kg == 0 && !(ABL & 64);
     auto prefetch_residual_wide = [&]() {
         if constexpr (WPREF) {
             auto grab = [&](int j0, int base, auto cf_tag) {
@@ -882,7 +886,7 @@ gemm_conv_kernel(const Params p) {
         }
         if constexpr (SQ) {
             bf16_t* Ct = p.Ct + (int64_t)bz * p.strideCt;
-            if (p.wide & 4) {
+            if (EK == 3 || (p.wide & 4)) {
                 constexpr int CF = (FN % 2 == 0) ? 2 : 1, SR = CF * 64 + 16, LPR = CF * 4, RPI = 64 / LPR, NP = 32 / RPI;
                 char* stg = smem + w * STG_MAX;
                 const int rr = lane / LPR, cc = (lane % LPR) * 8;
@@ -953,10 +957,10 @@ gemm_conv_kernel(const Params p) {
     }
 
     bf16_t* Cb = p.C + (int64_t)bz * p.strideC;
-    if (p.epilogue == TMIX_EPI_GEGLU) {
+    if (EK == 1 || (EK == 0 && p.epilogue == TMIX_EPI_GEGLU)) {
         // weight rows are interleaved in 16-row groups [value_j | gate_j]: within a 32-row fragment, accumulator
         // register groups g=0,1 (rows 0-15) are the value half and g=2,3 (rows 16-31) the gate half.
-        if (p.wide & 2) {
+        if (EK == 1 || (p.wide & 2)) {
             char* stg = smem + w * STG_MAX;
             auto chunk = [&](int i, int j0, auto cf_tag) {       // CF fragments -> CF * 16 output columns of one 32-row block
                 constexpr int CF = decltype(cf_tag)::value, OC = CF * 16, SR = OC * 2 + 16, LPR = OC / 8, RPI = 64 / LPR, NP = 32 / RPI;
@@ -1051,8 +1055,8 @@ gemm_conv_kernel(const Params p) {
     // LayerNorm producer side: {sum, sum of squares} of every row of this tile AS STORED (bf16-rounded), reduced over
     // the wave's fragments, the lane pair and the WG's wave columns in a fixed order, then written (not accumulated)
     // to stats_out[tile_n][m] -- one partial per column tile; the consumer adds the tiles_n partials.
-    float2* sto = p.stats_out ? (float2*)(p.stats_out + (int64_t)bz * p.strideStatsOut) : nullptr;
-    if (p.wide & 1) {
+    float2* sto = (!CONV && p.stats_out) ? (float2*)(p.stats_out + (int64_t)bz * p.strideStatsOut) : nullptr;      // (a convolution has no LayerNorm behind it)
+    if (EK >= 2 || (p.wide & 1)) {
         char* stg = smem + w * STG_MAX;
         float2* redw = (float2*)(smem + NW * STG_MAX);           // [WN][BM] row-statistics exchange, behind the patches
         const bool f32out = p.epilogue == TMIX_EPI_F32OUT;
@@ -1435,14 +1439,14 @@ struct TileCfg { int bm, bn; };
 // every SIMD hosts one math wave and one loader, and a K-tile's 36 LDS-DMA instructions are nine per loader
 constexpr int NUM_CFG = 21;
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0>
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
     constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4 + (CONV ? BN * 4 : 0)      // staging ring + fused-LayerNorm block + the tile's bias (+ time-embedding row)
                        + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
-    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS, CS>;
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS, CS, EK>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1462,10 +1466,16 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
 }
 
 
-// the same tiling with or without the column statistics of Params::cs_out (its own instantiation, see gemm_conv_kernel)
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1>
+// the instantiation of a tiling that holds what this launch needs and nothing else: the epilogue family EK (gemm_conv_kernel), with or without
+// the column statistics of Params::cs_out
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CSOK = 1>
 int launch_cs(Params& p, int batch, hipStream_t st) {
-    return p.cs_out ? launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1>(p, batch, st) : launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0>(p, batch, st);
+    const bool no_trans = p.n_trans_begin < 0;
+    if constexpr (CSOK) { if (p.cs_out) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2>(p, batch, st); }         // (validated: plain staged epilogue)
+    if constexpr (!CONV) { if (no_trans && p.epilogue == TMIX_EPI_GEGLU && (p.wide & 2)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 1>(p, batch, st); }
+    if (no_trans && p.epilogue != TMIX_EPI_GEGLU && (p.wide & 1)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2>(p, batch, st);
+    if constexpr (!CONV) { if (!no_trans && p.epilogue != TMIX_EPI_GEGLU && (p.wide & 1) && (p.wide & 4)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 3>(p, batch, st); }
+    return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 0>(p, batch, st);
 }
 
 // one launcher per group of tilings (defined in gemm_inst_<g>.hip); returns -999 when `cfg` is not in the group
