@@ -213,6 +213,13 @@ typedef struct {
     int32_t batch_bias_images;   /* consecutive images that share one batch_bias row (0/1: one row per image; the video
                                     UNet folds frames into B and has one time embedding per clip: = frames) */
     float* col_stats_out;        /* NULL or fp32 [B*Ho*Wo / 32][2][Cout]: as in tmix_gemm_desc (B*Ho*Wo %% 32 == 0, Cout %% 8 == 0) */
+    /* --- the 1x1 conv_shortcut of a ResnetBlock2D in the same launch (diffusers ResnetBlock2D.forward: conv2(h) + conv_shortcut(x); in the
+     * up-blocks x = cat[hidden, skip]): S1 / S2 = NULL or bf16 NHWC [B][H][W][S1_channels] / [..][S2_channels] (TMIX_CONV_S1 geometry only,
+     * channels %% 64 == 0, S2 only with S1), and Wt then holds rows [Cout][9*Cin + S1_channels + S2_channels] = [conv2 taps | shortcut
+     * weights over S1's channels | over S2's]; bias = conv2.bias + conv_shortcut.bias.  The K loop walks the two tensors' channels at the
+     * output pixel behind the nine taps: one accumulator, no shortcut GEMM, no residual round trip, and the concatenation is never written. */
+    const void* S1; const void* S2;
+    int32_t S1_channels, S2_channels;
 } tmix_conv_desc;
 int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
 

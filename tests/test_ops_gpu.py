@@ -466,6 +466,28 @@ def test_conv_leaves_groupnorm_column_statistics(ops, cfg, mode, B, H, W, Cin, C
     _colstats_close(cs, out)
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 7, 12, 13, 14, 15, 20])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,c1,c2,cs", [(2, 16, 16, 64, 128, 64, 0, False), (1, 32, 32, 128, 320, 192, 128, True), (3, 8, 8, 64, 72, 64, 64, False),
+                                                     (2, 16, 16, 320, 320, 640, 320, True)])
+def test_conv_with_shortcut_taps(ops, cfg, B, H, W, Cin, Cout, c1, c2, cs):
+    """ResnetBlock2D's conv2(h) + conv_shortcut(cat[x1, x2]) in ONE launch: the 1x1 taps ride behind the nine 3x3 taps (tmix_conv_desc.S1 / S2)"""
+    h = rnd(B, H, W, Cin, seed=80)
+    w = rnd(Cout, 3, 3, Cin, seed=81, scale=(9 * Cin) ** -0.5)
+    x1 = rnd(B, H, W, c1, seed=82)
+    x2 = rnd(B, H, W, c2, seed=83) if c2 else None
+    wsc = rnd(Cout, c1 + c2, seed=84, scale=(c1 + c2) ** -0.5)
+    bias = rnd(Cout, seed=85, dtype=torch.float32)
+    temb = rnd(B, Cout, seed=86, dtype=torch.float32)
+    csb = ops.colstats_buf(B * H * W, Cout, "cuda") if cs else None
+    out = ops.conv3x3(h, ops.shortcut_weight(w, wsc), bias=bias, batch_bias=temb, tile_cfg=cfg, shortcut=(x1, x2), col_stats_out=csb)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], -1)
+    ref = F.conv2d(h.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    ref = ref + xin @ wsc.float().T + temb[:, None, None, :]
+    close(out, ref)
+    if cs:
+        _colstats_close(csb, out)
+
+
 def test_column_statistics_reject_what_they_cannot_serve(ops):
     from tweediemix_amd import lib as L
     a, w = rnd(128, 64), rnd(128, 64)
@@ -473,6 +495,8 @@ def test_column_statistics_reject_what_they_cannot_serve(ops):
         ops.gemm(a, w, geglu=True, col_stats_out=torch.empty(4, 2, 128, device="cuda"))
     with pytest.raises(L.TmixError):                          # transposed region
         ops.gemm(a, w, out_t=torch.empty(128, 128, device="cuda", dtype=BF), n_trans_begin=0, col_stats_out=torch.empty(4, 2, 128, device="cuda"))
+    with pytest.raises(L.TmixError):                          # shortcut taps over a channel count that is not a multiple of the K-tile
+        ops.conv3x3(rnd(1, 8, 8, 64), ops.shortcut_weight(rnd(64, 3, 3, 64), rnd(64, 32)), shortcut=(rnd(1, 8, 8, 32), None))
     with pytest.raises(L.TmixError):                          # HW not a multiple of 32
         ops.groupnorm(rnd(1, 48, 64), rnd(64, dtype=torch.float32), rnd(64, dtype=torch.float32), colstats=(torch.empty(1, 2, 64, device="cuda"), None))
 

@@ -91,6 +91,28 @@ def test_groupnorm_statistics_from_the_producers_match_the_statistics_kernel(kin
     assert rel_l2(eps, ref) <= 2e-2 and rel_l2(eps, eps0) <= 1e-2
 
 
+@pytest.mark.parametrize("kind,hw", [("lora", (32, 32)), ("none", (8, 24))])
+def test_shortcut_in_the_conv_launch_matches_the_separate_gemm_and_concat(kind, hw, monkeypatch):
+    """the default plan runs conv_shortcut inside conv2's launch (shortcut taps) and never writes the up-blocks' concatenations;
+    TMIX_SHORTCUT_GEMM=1 is the form with a shortcut GEMM + residual and concat launches.  Same network, same weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    h, w = hw
+    B = 4 if kind == "lora" else 2
+    orc, plan, x, ehs, pooled, time_ids = make(kind, B, h, w, kind == "lora")
+    names = [fn.__name__ for fn, _a in plan.ops]
+    assert "tmix_concat_channels" not in names
+    eps = plan(x.cuda(), 500).float().cpu()
+    monkeypatch.setenv("TMIX_SHORTCUT_GEMM", "1")
+    _orc, plan0, *_ = make(kind, B, h, w, kind == "lora")
+    names0 = [fn.__name__ for fn, _a in plan0.ops]
+    assert names0.count("tmix_concat_channels") == 9 and len(names0) > len(names)
+    eps0 = plan0(x.cuda(), 500).float().cpu()
+    ref = orc.forward(x, 500, ehs, pooled, time_ids, routed=(kind == "lora"))
+    print(f"{kind} {hw}: {len(names)} vs {len(names0)} ops; fused vs separate rel_l2={rel_l2(eps, eps0):.3g}, vs oracle {rel_l2(eps, ref):.3g} / {rel_l2(eps0, ref):.3g}")
+    assert rel_l2(eps, ref) <= 2e-2 and rel_l2(eps, eps0) <= 1e-2
+
+
 @pytest.mark.parametrize("hw", [(16, 16), (8, 24)])
 def test_unet_plan_with_lora_in_low_rank_form_matches_oracle_and_the_merged_plan(hw):
     """UNetWeights(lora_mode="lowrank"): up(down(x)) as the routed projections' last K-tile (tmix_lora_down fills the pad columns,

@@ -198,10 +198,21 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
     p.rgb = d->batch_bias; p.rows_per_group = p.Ho * p.Wo * (d->batch_bias_images > 1 ? d->batch_bias_images : 1);
     p.n_trans_begin = -1;
     p.M = (int)M; p.N = d->Cout; p.K = p.ntaps * d->Cin;
+    if (d->S1 || d->S2) {            // shortcut taps behind the nine conv taps
+        const int c1 = d->S1_channels, c2 = d->S2 ? d->S2_channels : 0;
+        if (!d->S1 || d->mode != TMIX_CONV_S1 || c1 <= 0 || (c1 % BK) || c2 < 0 || (c2 % BK) || (d->S2 && c2 == 0) || !aligned16(d->S1) || (d->S2 && !aligned16(d->S2)) || d->residual)
+            TMIX_FAIL(TMIX_EINVAL, "conv3x3: shortcut taps need the stride-1 mode, S1 (S2 only with S1), channel counts that are multiples of %d, 16-byte alignment and no residual", BK);
+        if ((int64_t)d->B * d->H * d->W * (c1 > c2 ? c1 : c2) >= (1ll << 30) || (int64_t)d->Cout * (9ll * d->Cin + c1 + c2) >= (1ll << 30)) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: shortcut operand larger than 2 GiB");
+        p.S1 = (const bf16_t*)d->S1; p.S2 = (const bf16_t*)d->S2; p.c1s = c1; p.c2s = c2;
+        p.bytesS1 = (unsigned)((int64_t)d->B * d->H * d->W * c1 * 2); p.bytesS2 = (unsigned)((int64_t)d->B * d->H * d->W * c2 * 2);
+        p.K += c1 + c2;
+        p.ldw = p.K;
+    }
     p.epilogue = TMIX_EPI_NONE;
     p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
-    p.bytesW = (unsigned)((int64_t)d->Cout * p.ntaps * d->Cin * 2);
+    p.bytesW = (unsigned)((int64_t)d->Cout * p.K * 2);
     p.wide = (!getenv("TMIX_NARROW_EPILOGUE") && aligned16(d->Y) && (d->Cout % 8) == 0 && (!d->residual || aligned16(d->residual))) ? 1 : 0;
+    if (p.S1 && !p.wide) TMIX_FAIL(TMIX_EALIGN, "conv3x3: shortcut taps need the staged epilogue (16-byte aligned Y, Cout %% 8 == 0)");
     if (d->col_stats_out) {
         if ((M % TMIX_COLSTATS_ROWS) || !aligned16(d->col_stats_out) || !p.wide)
             TMIX_FAIL(TMIX_EINVAL, "conv3x3: col_stats_out needs B*Ho*Wo %% 32 == 0, Cout %% 8 == 0 and 16-byte aligned Y / residual");

@@ -91,6 +91,8 @@ struct Params {
     const char* pf; long long pf_bytes;                         // tmix_gemm_prefetch_next: the next launch's weights, touched in the prologue
     int pf_per;                                                 // 128-byte lines per touching thread (host-computed: a 64-bit division in every wave's prologue otherwise)
     float* cs_out;                                              // GroupNorm producer side: fp32 [M/32][2][N] column {sums | sums of squares} per 32-row block
+    // convolution with 1x1 SHORTCUT taps (SC): behind the nine 3x3 taps the K loop walks the channels of up to two more NHWC tensors at the output pixel
+    const bf16_t* S1; const bf16_t* S2; int c1s, c2s; unsigned bytesS1, bytesS2;
 };
 
 // LDS-DMA through a buffer descriptor: buffer_load_dwordx4 voff, rsrc, soff offen lds.  The per-lane part of the
@@ -130,13 +132,17 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() { asm volat
 // epilogue only, 2: the staged plain epilogue only (all its flavours), 3: the staged plain and the staged transposed form (q | k | V^T).  One kernel that can do everything carries every path's register demand: the
 // 256 x 320 tiling compiled with all families spills 35 VGPRs (144 bytes of scratch per lane, 179 KB of code), with the GEGLU family alone none
 // (227 VGPRs, 41 KB).  launch_cs picks the family from the launch's parameters; results are bit-identical (the same code, less of it).
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0>
+// SC = 1 (convolution only): the 1x1 shortcut of a ResnetBlock2D rides in the same K loop -- after the nine taps of conv2 the loop walks the channels of the
+// block's INPUT (one tensor, or the two halves of an up-block's concatenation, which then never has to be materialised) against weight rows
+// [conv2 | conv_shortcut]: out = conv2(h) + conv_shortcut(x) from one accumulator, no shortcut GEMM, no residual round trip, no concat launch.
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 // (HIP's second launch-bounds argument is the minimum number of waves per SIMD: a workgroup with a loader wave puts three
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
 __global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? (NS * (BM + BN) * 128 > 80 * 1024 ? 2 : 3) : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
 gemm_conv_kernel(const Params p) {
     static_assert(!PH || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
     static_assert(KS == 1 || (KS == 2 && !LW && !PH && !CONV), "in-workgroup split-K geometry");
+    static_assert(!SC || (CONV && !LW), "shortcut taps belong to the convolution");
     // PH = 2: the same loop on OCP fp8 (e4m3) operands: a slice row is still 64 bytes, i.e. 64 K values, and the eight
     // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
     // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
@@ -299,12 +305,23 @@ gemm_conv_kernel(const Params p) {
 
     const int nk = p.K / BK;
     int tap = 0, cc = 0;                              // conv K-tile cursor: tap (0..8), 64-channel chunk
-    const int cpt = CONV ? p.Cin / BK : 1;
+    int cpt = CONV ? p.Cin / BK : 1;                  // (SC: the chunks of the CURRENT tap -- the shortcut taps 9 / 10 have their own channel counts)
+    const int ntaps_all = SC ? p.ntaps + (p.c1s > 0) + (p.c2s > 0) : p.ntaps;
 
     // conv: the per-lane byte offset of a tap is computed once per tap (when the 64-channel cursor cc wraps);
     // the channel chunk rides in the scalar soffset.  Padding taps get an offset beyond num_records (-> zeros).
     unsigned cvo[RA];
-    auto conv_tap_offsets = [&]() {
+    auto conv_tap_offsets = [&]() __attribute__((always_inline)) {      // (outlined, it takes the per-row arrays through scratch memory)
+        if constexpr (SC) {
+            if (tap >= p.ntaps) {                      // shortcut tap: the output pixel itself, Cs channels (stride-1 geometry: H x W = Ho x Wo)
+                const int Cs = tap == p.ntaps ? p.c1s : p.c2s;
+#pragma unroll
+                for (int r = 0; r < RA; ++r)
+                    cvo[r] = (unsigned)(((pb[r] * p.H + py[r]) * p.Wd + px[r]) * Cs + asw[r]) * 2u;
+                cpt = Cs / BK;
+                return;
+            }
+        }
         // TMIX_CONV_T3: a (3,1,1) kernel over the first (frame) axis only -- 3 taps, kx fixed at the centre
         const int ky = p.mode == TMIX_CONV_T3 ? tap : tap / 3, kx = p.mode == TMIX_CONV_T3 ? 1 : tap - ky * 3;
 #pragma unroll
@@ -321,9 +338,22 @@ gemm_conv_kernel(const Params p) {
     };
     if constexpr (CONV) { if (stager) conv_tap_offsets(); }
 
-    auto stage = [&](int buf, int kt) {
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         char* sA = smem + buf * STAGE;
         char* sW = sA + A_TILE;
+        bool a_done = false;
+        if constexpr (CONV && SC) {
+            // the A source of this K-tile: the conv input for the nine taps, then the shortcut tensors.  The cursor is wave-uniform (said explicitly),
+            // and the choice is made on plain pointers -- a select between buffer RESOURCES goes through scratch memory and waterfall loops
+            const int tap_u = __builtin_amdgcn_readfirstlane(tap);
+            const void* base = tap_u < p.ntaps ? (const void*)Ab : (tap_u == p.ntaps ? (const void*)p.S1 : (const void*)p.S2);
+            const unsigned bytes = tap_u < p.ntaps ? p.bytesA : (tap_u == p.ntaps ? p.bytesS1 : p.bytesS2);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+            a_done = true;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) blds16(rs, cvo[r], (unsigned)cc * (BK * 2), sA + slot_a(r) * 1024);
+        }
+        if (!a_done)
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + slot_a(r) * 1024);
@@ -337,7 +367,7 @@ gemm_conv_kernel(const Params p) {
                                      (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
             else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
         }
-        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < p.ntaps) conv_tap_offsets(); } }
+        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < ntaps_all) conv_tap_offsets(); } }
     };
 
     // ---- loader wave (LW): leaves here, before any math-wave state (accumulators, fragments) becomes live
@@ -1439,14 +1469,14 @@ struct TileCfg { int bm, bn; };
 // every SIMD hosts one math wave and one loader, and a K-tile's 36 LDS-DMA instructions are nine per loader
 constexpr int NUM_CFG = 21;
 
-template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0>
+template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
     constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4 + (CONV ? BN * 4 : 0)      // staging ring + fused-LayerNorm block + the tile's bias (+ time-embedding row)
                        + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
-    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS, CS, EK>;
+    auto kern = gemm_conv_kernel<BM, BN, WM, WN, NS, CONV, LW, PH, KS, CS, EK, SC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1471,6 +1501,9 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CSOK = 1>
 int launch_cs(Params& p, int batch, hipStream_t st) {
     const bool no_trans = p.n_trans_begin < 0;
+    if constexpr (CONV == 1 && !LW) {                 // shortcut taps (validated: stride-1 conv, staged plain epilogue)
+        if (p.S1) return p.cs_out ? launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2, 1>(p, batch, st) : launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2, 1>(p, batch, st);
+    }
     if constexpr (CSOK) { if (p.cs_out) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2>(p, batch, st); }         // (validated: plain staged epilogue)
     if constexpr (!CONV) { if (no_trans && p.epilogue == TMIX_EPI_GEGLU && (p.wide & 2)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 1>(p, batch, st); }
     if (no_trans && p.epilogue != TMIX_EPI_GEGLU && (p.wide & 1)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2>(p, batch, st);

@@ -52,7 +52,7 @@ class ConvDesc(C.Structure):
     """mirror of tmix_conv_desc"""
     _fields_ = [("X", vp), ("Wt", vp), ("Y", vp), ("bias", vp), ("batch_bias", vp), ("residual", vp),
                 ("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("mode", i32), ("tile_cfg", i32),
-                ("batch_bias_images", i32), ("col_stats_out", vp)]
+                ("batch_bias_images", i32), ("col_stats_out", vp), ("S1", vp), ("S2", vp), ("S1_channels", i32), ("S2_channels", i32)]
 
 
 SIGNATURES = {

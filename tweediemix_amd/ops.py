@@ -237,13 +237,22 @@ def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, f8_cop
     return out if out is not None else kw.get("out_f32")
 
 
-def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0, bias_images=1, col_stats_out=None):
+def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0, bias_images=1, col_stats_out=None,
+                   shortcut=None):
     """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous ([Cout,3,Cin] for the temporal CONV_T3,
-    where x is [clips, frames, h*w, Cin])."""
+    where x is [clips, frames, h*w, Cin]).
+    shortcut: (s1, s2 or None) -- NHWC tensors whose 1x1 conv_shortcut rides in the same K loop; w is then the 2-d [Cout, 9*Cin + C(s1) + C(s2)]
+    matrix [conv taps | shortcut weights] (shortcut_weight) and bias the sum of the two biases."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     assert x.dtype == BF16 and w.dtype == BF16 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
-    assert tuple(w.shape) == ((Cout, 3, Cin) if mode == L.CONV_T3 else (Cout, 3, 3, Cin))
+    if shortcut is not None:
+        s1, s2 = shortcut
+        c1, c2 = s1.shape[-1], (0 if s2 is None else s2.shape[-1])
+        assert mode == L.CONV_S1 and tuple(w.shape) == (Cout, 9 * Cin + c1 + c2) and residual is None
+        assert s1.dtype == BF16 and s1.is_contiguous() and s1.numel() == B * H * W * c1 and (s2 is None or (s2.dtype == BF16 and s2.is_contiguous() and s2.numel() == B * H * W * c2))
+    else:
+        assert tuple(w.shape) == ((Cout, 3, Cin) if mode == L.CONV_T3 else (Cout, 3, 3, Cin))
     d = L.ConvDesc()
     d.X, d.Wt, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.batch_bias, d.residual = _p(bias), _p(batch_bias), _p(residual)
@@ -254,21 +263,31 @@ def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.
         cs = col_stats_out
         assert cs.dtype == torch.float32 and cs.is_contiguous() and tuple(cs.shape) == (out.numel() // Cout // COLSTATS_ROWS, 2, Cout)
         d.col_stats_out = cs.data_ptr()
+    if shortcut is not None:
+        d.S1, d.S1_channels = s1.data_ptr(), c1
+        if s2 is not None:
+            d.S2, d.S2_channels = s2.data_ptr(), c2
     return d
+
+
+def shortcut_weight(w_conv, w_sc):
+    """[Cout, 9*Cin + Csc]: the OHWI taps of a 3x3 conv followed by the [Cout, Csc] weights of the 1x1 shortcut that shares its launch"""
+    Cout = w_conv.shape[0]
+    return torch.cat([w_conv.reshape(Cout, -1), w_sc.reshape(Cout, -1)], dim=1).contiguous()
 
 
 def conv_out_hw(H, W, mode):
     return (H // 2, W // 2) if mode in (L.CONV_S2, L.CONV_S2A) else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
 
 
-def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0, col_stats_out=None):
+def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0, col_stats_out=None, shortcut=None):
     _need_cuda(x, w)
     lib = L.load()
     B, H, W, _ = x.shape
     Ho, Wo = conv_out_hw(H, W, mode)
     if out is None:
         out = torch.empty(B, Ho, Wo, w.shape[0], device=x.device, dtype=BF16)
-    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode, tile_cfg, col_stats_out=col_stats_out)
+    d = make_conv_desc(x, w, out, bias, batch_bias, residual, mode, tile_cfg, col_stats_out=col_stats_out, shortcut=shortcut)
     L.check(lib.tmix_conv3x3_nhwc(C.byref(d), _stream()), "tmix_conv3x3_nhwc")
     return out
 

@@ -251,6 +251,15 @@ class UNetWeights:
             self._tproj = (w, b, torch.tensor(st, device=w.device, dtype=torch.int32), names)
         return self._tproj
 
+    def conv2_with_shortcut(self, name):
+        """(weight [Co, 9*Co + Ci] bf16, bias [Co] fp32) of resnet `name`: conv2's taps followed by conv_shortcut's 1x1 weights, and the sum of the two
+        biases -- the operands of a tmix_conv3x3_nhwc launch with shortcut taps (ResnetBlock2D.forward: conv2(h) + conv_shortcut(x)); built once."""
+        k = name + ".conv2+shortcut"
+        if k + ".weight" not in self.t:
+            self.t[k + ".weight"] = ops.shortcut_weight(self.t[name + ".conv2.weight"], self.t[name + ".conv_shortcut.weight"])
+            self.t[k + ".bias"] = (self.t[name + ".conv2.bias"] + self.t[name + ".conv_shortcut.bias"]).contiguous()
+        return self.t[k + ".weight"], self.t[k + ".bias"]
+
     def fp8(self, key, rows=None):
         """(e4m3 bytes, E8M0 row scales) of weight `key` ([N,K], or the [R,N,K] stack gathered by `rows`), quantised once per
         tensor by tmix_quantize_fp8_rows -- the operands of tmix_gemm_fp8 (`--dtype fp8`)."""
@@ -436,6 +445,9 @@ class UNetPlan:
         # GroupNorm statistics come from the launch that WRITES the normalised tensor (col_stats_out of the conv / proj_out epilogue), so a
         # norm is two launches (combine partials, apply) and one pass over x instead of three and two (TMIX_GN_STATS_KERNEL=1: the old form)
         self._gn_fused = not os.environ.get("TMIX_GN_STATS_KERNEL")
+        # conv_shortcut rides in conv2's K loop (tmix_conv_desc.S1 / S2): no shortcut GEMM, and the up-blocks' concatenations are never written
+        # (TMIX_SHORTCUT_GEMM=1: the separate GEMM + concat launches)
+        self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")
         self._tunable = []                  # (index into self.ops, kind, descriptor) of every GEMM / conv launch
         self._ln_links = []                 # (producer desc, [consumer descs]): ln_parts follows the producer's tiling
         self._build()
@@ -530,17 +542,22 @@ class UNetPlan:
         owner._cs = ((cs, Cc),)
         return cs
 
-    def _gn(self, x, Cc, HW, name, eps, silu, out=None):
+    def _gn(self, x, Cc, HW, name, eps, silu, out=None, x2=None):
+        """x2: a second tensor normalised as the channel-concatenation [x | x2] (Cc counts both)"""
         out = out if out is not None else self.arena.get(self.B, HW, Cc)
         W = self.W
+        C2 = 0 if x2 is None else x2.shape[-1]
         parts = getattr(x, "_cs", None)
+        if x2 is not None:
+            p2 = getattr(x2, "_cs", None)
+            parts = (parts[0], p2[0]) if parts and p2 and len(parts) == 1 and len(p2) == 1 else None
         if parts and sum(c for _t, c in parts) == Cc:
             (cs1, c1), (cs2, c2) = (parts[0], parts[1]) if len(parts) == 2 else (parts[0], (None, 0))
-            self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+            self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out.data_ptr(), W[name + ".weight"].data_ptr(),
                        W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu),
                        cs1.data_ptr(), c1, cs2.data_ptr() if cs2 is not None else None, c2)
         else:
-            self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+            self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out.data_ptr(), W[name + ".weight"].data_ptr(),
                        W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu))
         self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", self.B, HW, Cc))
         return out
@@ -625,16 +642,23 @@ class UNetPlan:
             self.arena.put(*owned)                  # stream-ordered: free for ops planned after this GEMM
         return out
 
-    def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None, bias_images=1):
+    def _conv(self, x, wname, Hh, Ww, Cin, Cout, mode=L.CONV_S1, batch_bias=None, residual=None, bias_images=1, shortcut=None):
+        """shortcut: (resnet name, x1, x2 or None) -- the block's input(s), whose 1x1 conv_shortcut rides in this launch's K loop"""
         Ho, Wo = ops.conv_out_hw(Hh, Ww, mode)
         out = self.arena.get(self.B, Ho * Wo, Cout)
-        d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Cin), self.W[wname + ".weight"], out.view(self.B, Ho, Wo, Cout),
-                               self.W[wname + ".bias"], batch_bias, residual, mode, bias_images=bias_images,
-                               col_stats_out=self._colstats(out, self.B * Ho * Wo, Ho * Wo, Cout))      # every conv output of this network feeds a GroupNorm
+        w, bias, sc, csc = self.W[wname + ".weight"], self.W[wname + ".bias"], None, 0
+        if shortcut is not None:
+            w, bias = self.W.conv2_with_shortcut(shortcut[0])
+            sc = (shortcut[1], shortcut[2])
+            csc = w.shape[1] - 9 * Cin
+        d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Cin), w, out.view(self.B, Ho, Wo, Cout),
+                               bias, batch_bias, residual, mode, bias_images=bias_images,
+                               col_stats_out=self._colstats(out, self.B * Ho * Wo, Ho * Wo, Cout),      # every conv output of this network feeds a GroupNorm
+                               shortcut=sc)
         self.keep.append(d)
-        self._hint_weights(self.W[wname + ".weight"])
+        self._hint_weights(w)
         self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
-        fl = 2 * self.B * Ho * Wo * Cout * 9 * Cin
+        fl = 2 * self.B * Ho * Wo * Cout * (9 * Cin + csc)
         self.flops += fl
         self.launches["conv"].append((d, fl))
         self._tunable.append((len(self.ops) - 1, "conv", d))
@@ -675,16 +699,26 @@ class UNetPlan:
         return self._vt[key]
 
     # ------------------------------------------------------------------ blocks
-    def _resnet(self, x, Ci, Co, Hh, Ww, name, emb):
+    def _sc_ok(self, Ci, Co, c1, c2=0):
+        return getattr(self, "_sc_fused", False) and Ci != Co and c1 % 64 == 0 and c2 % 64 == 0
+
+    def _resnet(self, x, Ci, Co, Hh, Ww, name, emb, x2=None):
+        """x2: the block's input is the channel-concatenation [x | x2] (up-blocks; Ci counts both), which is never written: norm1 reads the two
+        tensors, and conv_shortcut's two halves ride in conv2's K loop (only when _sc_ok)"""
         B, W, A = self.B, self.W, self.arena
         HW = Hh * Ww
-        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True)
+        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True, x2=x2)
         temb = self._temb[name]                     # [B, Co] fp32: this block's section of the one stacked time_emb_proj launch
         assert temb.shape == (B, Co)
         h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb)
         A.put(h1)
         h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
         A.put(h2)
+        if self._sc_ok(Ci, Co, x.shape[-1], 0 if x2 is None else x2.shape[-1]):
+            out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, shortcut=(name, x, x2))
+            A.put(h3)
+            return out
+        assert x2 is None
         if Ci != Co:
             sc = A.get(B, HW, Co)
             self._gemm(x.view(B * HW, Ci), W[name + ".conv_shortcut.weight"], sc.view(B * HW, Co), bias=W[name + ".conv_shortcut.bias"])
@@ -874,10 +908,15 @@ class UNetPlan:
             bi = nb - 1 - ui
             for j in range(cfg.layers_per_block + 1):
                 sk, cs = skips.pop()
-                xc = self._cat(x, ci, sk, cs, Hh * Ww)
-                A.put(x, sk)
-                x = self._resnet(xc, ci + cs, co, Hh, Ww, f"up_blocks.{ui}.resnets.{j}", emb)
-                A.put(xc)
+                if self._sc_ok(ci + cs, co, ci, cs):                 # no concatenation: norm1 and conv2's shortcut taps read the two tensors
+                    xn = self._resnet(x, ci + cs, co, Hh, Ww, f"up_blocks.{ui}.resnets.{j}", emb, x2=sk)
+                    A.put(x, sk)
+                    x = xn
+                else:
+                    xc = self._cat(x, ci, sk, cs, Hh * Ww)
+                    A.put(x, sk)
+                    x = self._resnet(xc, ci + cs, co, Hh, Ww, f"up_blocks.{ui}.resnets.{j}", emb)
+                    A.put(xc)
                 if cfg.transformer_layers[bi]:
                     x2 = self._t2d(x, co, Hh, Ww, f"up_blocks.{ui}.attentions.{j}", cfg.transformer_layers[bi])
                     A.put(x)

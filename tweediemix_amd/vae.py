@@ -11,7 +11,6 @@ The 1/scaling_factor and post_quant_conv are folded into a per-pixel 4x4 map ins
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
@@ -161,48 +160,30 @@ class VAEDecoderPlan:
     def _emit(self, fn, *a):
         self.ops.append((fn, a))
 
-    def _colstats(self, owner, rows, HW, Cc):
-        """GroupNorm column partials written by the launch that stores `owner` (as UNetPlan._colstats; released with the tensor)"""
-        if os.environ.get("TMIX_GN_STATS_KERNEL") or HW % ops.COLSTATS_ROWS or HW > ops.COLSTATS_MAX_HW or rows % ops.COLSTATS_ROWS or Cc % 8:
-            return None
-        cs = self.arena.get(rows // ops.COLSTATS_ROWS, 2, Cc, dtype=F32)
-        owner._cs = ((cs, Cc),)
-        return cs
-
     def _gn(self, x, Cc, HW, name, silu):
         out = self.arena.get(self.B, HW, Cc)
-        parts = getattr(x, "_cs", None)
-        if parts and len(parts) == 1 and parts[0][1] == Cc:         # statistics from the producer's epilogue: no pass over x for them
-            self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc, None, 0, out.data_ptr(), self.t[name + ".weight"].data_ptr(),
-                       self.t[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg["groups"], 1e-6, int(silu),
-                       parts[0][0].data_ptr(), Cc, None, 0)
-            return out
         self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), self.t[name + ".weight"].data_ptr(),
                    self.t[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg["groups"], 1e-6, int(silu))
         return out
 
-    def _conv(self, x, name, Hh, Ww, Ci, Co, mode=L.CONV_S1, residual=None, gn_next=True):
+    def _conv(self, x, name, Hh, Ww, Ci, Co, mode=L.CONV_S1, residual=None):
         Ho, Wo = ops.conv_out_hw(Hh, Ww, mode)
         out = self.arena.get(self.B, Ho * Wo, Co)
         d = ops.make_conv_desc(x.view(self.B, Hh, Ww, Ci), self.t[name + ".weight"], out.view(self.B, Ho, Wo, Co),
-                               self.t[name + ".bias"], None, residual, mode,
-                               col_stats_out=self._colstats(out, self.B * Ho * Wo, Ho * Wo, Co) if gn_next else None)
+                               self.t[name + ".bias"], None, residual, mode)
         self.keep.append(d)
         self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
         self.flops += 2 * self.B * Ho * Wo * Co * 9 * Ci
         return out
 
-    def _gemm(self, a, w, out, cs_owner=None, **kw):
-        if cs_owner is not None:                    # the [B, HW, N] tensor `out` is a view of: a GroupNorm reads it next
-            kw["col_stats_out"] = self._colstats(cs_owner, out.shape[0], cs_owner.shape[1], out.shape[1])
+    def _gemm(self, a, w, out, **kw):
         d = ops.make_gemm_desc(a, w, out, **kw)
         self.keep.append(d)
         self._emit(self.lib.tmix_gemm_bf16, C.byref(d))
         self.flops += 2 * d.M * d.N * d.K * d.batch
         return d
 
-    def _resnet(self, x, Ci, Co, Hh, Ww, name, gn_next=True):
-        """gn_next: a GroupNorm reads the block's output (False in front of an up- / downsampler conv: no column partials then)"""
+    def _resnet(self, x, Ci, Co, Hh, Ww, name):
         A, B = self.arena, self.B
         HW = Hh * Ww
         h1 = self._gn(x, Ci, HW, name + ".norm1", True)
@@ -215,7 +196,7 @@ class VAEDecoderPlan:
             self._gemm(x.view(B * HW, Ci), self.t[name + ".conv_shortcut.weight"], sc.view(B * HW, Co), bias=self.t[name + ".conv_shortcut.bias"])
         else:
             sc = x
-        out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, residual=sc, gn_next=gn_next)
+        out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, residual=sc)
         A.put(h3)
         if Ci != Co:
             A.put(sc)
@@ -245,7 +226,7 @@ class VAEDecoderPlan:
         A.put(qk)
         out = A.get(B, S, Cc)
         self._gemm(ao.view(B * S, Cc), t[name + ".to_out.0.weight"], out.view(B * S, Cc), bias=t[name + ".to_out.0.bias"],
-                   residual=x.view(B * S, Cc), cs_owner=out)
+                   residual=x.view(B * S, Cc))
         A.put(ao)
         return out
 
@@ -262,8 +243,7 @@ class VAEDecoderPlan:
         ci = ch[0]
         for i, co in enumerate(ch):
             for j in range(cfg["layers_per_block"] + 1):
-                x2 = self._resnet(x, ci, co, Hh, Ww, f"decoder.up_blocks.{i}.resnets.{j}",
-                                  gn_next=not (j == cfg["layers_per_block"] and i < len(ch) - 1))
+                x2 = self._resnet(x, ci, co, Hh, Ww, f"decoder.up_blocks.{i}.resnets.{j}")
                 A.put(x)
                 x, ci = x2, co
             if i < len(ch) - 1:
@@ -360,8 +340,7 @@ class VAEEncoderPlan(VAEDecoderPlan):
         ci = ch[0]
         for i, co in enumerate(ch):
             for j in range(cfg["layers_per_block"]):
-                x2 = self._resnet(x, ci, co, Hh, Ww, f"encoder.down_blocks.{i}.resnets.{j}",
-                                  gn_next=not (j == cfg["layers_per_block"] - 1 and i < len(ch) - 1))
+                x2 = self._resnet(x, ci, co, Hh, Ww, f"encoder.down_blocks.{i}.resnets.{j}")
                 A.put(x)
                 x, ci = x2, co
             if i < len(ch) - 1:
