@@ -122,6 +122,14 @@ class I2VWeights:
     def __getitem__(self, k):
         return self.t[k]
 
+    def conv2_with_shortcut(self, name):
+        """as UNetWeights.conv2_with_shortcut: ([Co, 9*Co + Ci] rows [conv2 taps | conv_shortcut], the two biases' sum), built once"""
+        k = name + ".conv2+shortcut"
+        if k + ".weight" not in self.t:
+            self.t[k + ".weight"] = ops.shortcut_weight(self.t[name + ".conv2.weight"], self.t[name + ".conv_shortcut.weight"])
+            self.t[k + ".bias"] = (self.t[name + ".conv2.bias"] + self.t[name + ".conv_shortcut.bias"]).contiguous()
+        return self.t[k + ".weight"], self.t[k + ".bias"]
+
 
 @torch.no_grad()
 def conditioning(W: I2VWeights, fps, image_latents, image_embeddings, encoder_hidden_states):
@@ -219,6 +227,7 @@ class I2VPlan(UNetPlan):
         self.lowrank = False                             # (no LoRA routing in the video UNet; UNetPlan's emitters ask)
         self._gn_fused = False                           # GroupNorm statistics stay with the statistics kernel here: the temporal norms span 16 frames
                                                          # (86,016 rows per clip, beyond ops.COLSTATS_MAX_HW) and the injection sites rewrite resnet outputs in place
+        self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")      # conv_shortcut in conv2's launch, no concat launches (UNetPlan._resnet)
         self.lib, self.dev = L.load(), W.device
         dev = self.dev
         self.ops, self.keep, self.arena = [], [], _Arena(dev)
@@ -246,30 +255,15 @@ class I2VPlan(UNetPlan):
             self.autotune()
 
     # ------------------------------------------------------------------ emitters the image UNet did not need
-    def _resnet(self, x, Ci, Co, Hh, Ww, name, emb):
-        """ResnetBlock2D as in the image UNet, except that the time embedding exists once per CLIP ([clips, T]): its
+    def _time_bias(self, name, Co, emb):
+        """ResnetBlock2D as in the image UNet (UNetPlan._resnet), except that the time embedding exists once per CLIP ([clips, T]): its
         projection is added to every frame of the clip through the conv's batch_bias_images."""
-        B, W, A = self.B, self.W, self.arena
-        HW = Hh * Ww
-        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True)
+        W = self.W
         temb = torch.empty(self.clips, Co, device=self.dev, dtype=F32)
         self.keep.append(temb)
         self._emit(self.lib.tmix_linear_small, emb.data_ptr(), W[name + ".time_emb_proj.weight"].data_ptr(),
                    W[name + ".time_emb_proj.bias"].data_ptr(), None, temb.data_ptr(), self.clips, Co, self.cfg.time_embed_dim, 1, 0)
-        h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb, bias_images=self.frames)
-        A.put(h1)
-        h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
-        A.put(h2)
-        if Ci != Co:
-            sc = A.get(B, HW, Co)
-            self._gemm(x.view(B * HW, Ci), W[name + ".conv_shortcut.weight"], sc.view(B * HW, Co), bias=W[name + ".conv_shortcut.bias"])
-        else:
-            sc = x
-        out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, residual=sc)
-        A.put(h3)
-        if Ci != Co:
-            A.put(sc)
-        return out
+        return temb, self.frames
 
     def _gn_b(self, x, Bn, Cc, HW, name, eps, silu):
         out = self.arena.get(*x.shape)
@@ -366,8 +360,8 @@ class I2VPlan(UNetPlan):
         A.put(x)
         x = x2
 
-        def layer(x, ci, co, pfx, j, attn):
-            y = self._resnet(x, ci, co, Hh, Ww, f"{pfx}.resnets.{j}", emb)
+        def layer(x, ci, co, pfx, j, attn, x2=None):
+            y = self._resnet(x, ci, co, Hh, Ww, f"{pfx}.resnets.{j}", emb, x2=x2)
             self._inject_site(y, f"{pfx}.resnets.{j}", Hh * Ww * co)
             y2 = self._temp_conv(y, co, Hh * Ww, f"{pfx}.temp_convs.{j}")
             A.put(y)
@@ -403,10 +397,15 @@ class I2VPlan(UNetPlan):
             co = ch[bi]
             for j in range(cfg.layers_per_block + 1):
                 sk, cs = skips.pop()
-                xc = self._cat(x, ci, sk, cs, Hh * Ww)
-                A.put(x, sk)
-                x = layer(xc, ci + cs, co, f"up_blocks.{ui}", j, cfg.attn_levels[bi])
-                A.put(xc)
+                if self._sc_ok(ci + cs, co, ci, cs):             # no concatenation: norm1 and conv2's shortcut taps read the two tensors
+                    xn = layer(x, ci + cs, co, f"up_blocks.{ui}", j, cfg.attn_levels[bi], x2=sk)
+                    A.put(x, sk)
+                    x = xn
+                else:
+                    xc = self._cat(x, ci, sk, cs, Hh * Ww)
+                    A.put(x, sk)
+                    x = layer(xc, ci + cs, co, f"up_blocks.{ui}", j, cfg.attn_levels[bi])
+                    A.put(xc)
                 ci = co
             if ui < nb - 1:
                 x2 = self._conv(x, f"up_blocks.{ui}.upsamplers.0.conv", Hh, Ww, co, co, mode=L.CONV_UP2)

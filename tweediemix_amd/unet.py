@@ -699,6 +699,12 @@ class UNetPlan:
         return self._vt[key]
 
     # ------------------------------------------------------------------ blocks
+    def _time_bias(self, name, Co, emb):
+        """(time_emb_proj(SiLU(emb)) rows for resnet `name` as conv1's batch_bias, consecutive images that share a row)"""
+        temb = self._temb[name]                     # [B, Co] fp32: this block's section of the one stacked time_emb_proj launch
+        assert temb.shape == (self.B, Co)
+        return temb, 1
+
     def _sc_ok(self, Ci, Co, c1, c2=0):
         return getattr(self, "_sc_fused", False) and Ci != Co and c1 % 64 == 0 and c2 % 64 == 0
 
@@ -708,9 +714,8 @@ class UNetPlan:
         B, W, A = self.B, self.W, self.arena
         HW = Hh * Ww
         h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True, x2=x2)
-        temb = self._temb[name]                     # [B, Co] fp32: this block's section of the one stacked time_emb_proj launch
-        assert temb.shape == (B, Co)
-        h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb)
+        temb, per = self._time_bias(name, Co, emb)
+        h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb, bias_images=per)
         A.put(h1)
         h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
         A.put(h2)
