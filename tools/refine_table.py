@@ -9,6 +9,7 @@ ap.add_argument("src"); ap.add_argument("dst")
 ap.add_argument("--cobatch", type=int, default=0); ap.add_argument("--top", type=int, default=40); ap.add_argument("--reps", type=int, default=9)
 ap.add_argument("--cands", default="")       # e.g. 2,12,20,21: only these tilings are tried (default: every candidate)
 ap.add_argument("--kinds", default="lora,custom")
+ap.add_argument("--only-cobatch", action="store_true")       # skip the single-seed plans (refine the N-seed entries only)
 a = ap.parse_args()
 os.environ["TMIX_TUNE_FILE"] = a.src
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +17,7 @@ import torch
 import bench
 from tweediemix_amd import unet as U
 dev = torch.device("cuda:0")
-for seeds in ([1] + ([a.cobatch] if a.cobatch else [])):
+for seeds in (([] if a.only_cobatch else [1]) + ([a.cobatch] if a.cobatch else [])):
     for kind in a.kinds.split(","):
         args = argparse.Namespace(kind=kind, res=1024, tiny=False, no_graphs=True, streams=1, seeds_per_gpu=seeds, dtype="bf16")
         tw, _ = bench.build_sampler(args, kind, dev, seed=7)

@@ -107,6 +107,27 @@ __device__ __forceinline__ void prof_leave(unsigned long long* slot, int detail,
     }
 }
 
+// Touch every 64-byte line of the kernel-argument block at kernel entry.  A launch's arguments are cold in the scalar cache, and the compiler loads
+// the fields of a large by-value parameter struct where it first needs them -- one s_load + s_waitcnt round trip after the other down the prologue
+// (the GEMM kernel: ~20 of them in front of the first LDS-DMA request).  With all lines requested back to back the misses overlap and the later
+// loads hit.  BYTES = sizeof(the kernel's parameter struct).
+template <int BYTES> __device__ __forceinline__ void kernarg_touch() {
+    const __attribute__((address_space(4))) void* ka = __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LINES = (BYTES + 63) / 64;
+    static_assert(LINES <= 10, "kernarg block larger than expected");
+    unsigned t;
+    if constexpr (LINES > 0) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 1) asm volatile("s_load_dword %0, %1, 0x40" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 2) asm volatile("s_load_dword %0, %1, 0x80" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 3) asm volatile("s_load_dword %0, %1, 0xc0" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 4) asm volatile("s_load_dword %0, %1, 0x100" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 5) asm volatile("s_load_dword %0, %1, 0x140" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 6) asm volatile("s_load_dword %0, %1, 0x180" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 7) asm volatile("s_load_dword %0, %1, 0x1c0" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 8) asm volatile("s_load_dword %0, %1, 0x200" : "=s"(t) : "s"(ka) : "memory");
+    if constexpr (LINES > 9) asm volatile("s_load_dword %0, %1, 0x240" : "=s"(t) : "s"(ka) : "memory");
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids land on
 // the same XCD (hardware places physical id b on XCD b % 8).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -167,6 +167,9 @@ gemm_conv_kernel(const Params p) {
     static_assert(PH || (NS - 2) * L <= 63, "vmcnt immediate");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef TMIX_NO_KERNARG_TOUCH
+    kernarg_touch<(int)sizeof(Params)>();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
