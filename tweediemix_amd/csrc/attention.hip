@@ -87,6 +87,9 @@ constexpr int NSP = 4;
 constexpr int SMEM_P = NSP * STAGE;
 
 __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams p) {
+#ifndef TMIX_NO_KERNARG_TOUCH
+    kernarg_touch<(int)sizeof(AttnParams)>();
+#endif
     constexpr int LOADS = 4;             // LDS-DMA instructions per wave per tile (16 KiB tile, 1 KiB per instruction)
     constexpr int NR = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,6 +341,9 @@ constexpr int SQW = 64;              // queries per wave
 // over the 256 CUs (B = 4, 20 heads, 1024 queries: 1280 waves = 256 workgroups of five, one per CU, where 320 workgroups of four ran
 // 1.25 rounds).
 __global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) {
+#ifndef TMIX_NO_KERNARG_TOUCH
+    kernarg_touch<(int)sizeof(AttnParams)>();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;

@@ -112,20 +112,24 @@ __device__ __forceinline__ void prof_leave(unsigned long long* slot, int detail,
 // (the GEMM kernel: ~20 of them in front of the first LDS-DMA request).  With all lines requested back to back the misses overlap and the later
 // loads hit.  BYTES = sizeof(the kernel's parameter struct).
 template <int BYTES> __device__ __forceinline__ void kernarg_touch() {
-    const __attribute__((address_space(4))) void* ka = __builtin_amdgcn_kernarg_segment_ptr();
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
     constexpr int LINES = (BYTES + 63) / 64;
-    static_assert(LINES <= 10, "kernarg block larger than expected");
-    unsigned t;
-    if constexpr (LINES > 0) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 1) asm volatile("s_load_dword %0, %1, 0x40" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 2) asm volatile("s_load_dword %0, %1, 0x80" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 3) asm volatile("s_load_dword %0, %1, 0xc0" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 4) asm volatile("s_load_dword %0, %1, 0x100" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 5) asm volatile("s_load_dword %0, %1, 0x140" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 6) asm volatile("s_load_dword %0, %1, 0x180" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 7) asm volatile("s_load_dword %0, %1, 0x1c0" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 8) asm volatile("s_load_dword %0, %1, 0x200" : "=s"(t) : "s"(ka) : "memory");
-    if constexpr (LINES > 9) asm volatile("s_load_dword %0, %1, 0x240" : "=s"(t) : "s"(ka) : "memory");
+    static_assert(LINES >= 1 && LINES <= 8, "kernarg block larger than expected");
+    // ONE statement: the loads and the wait for them (scalar loads return asynchronously -- the compiler must not reuse a destination before then)
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile("s_load_dword %0, %8, 0x0\n\t"
+                 "s_load_dword %1, %8, %9\n\t"
+                 "s_load_dword %2, %8, %10\n\t"
+                 "s_load_dword %3, %8, %11\n\t"
+                 "s_load_dword %4, %8, %12\n\t"
+                 "s_load_dword %5, %8, %13\n\t"
+                 "s_load_dword %6, %8, %14\n\t"
+                 "s_load_dword %7, %8, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+                 : "s"(ka), "n"(LINES > 1 ? 0x40 : 0), "n"(LINES > 2 ? 0x80 : 0), "n"(LINES > 3 ? 0xc0 : 0), "n"(LINES > 4 ? 0x100 : 0),
+                   "n"(LINES > 5 ? 0x140 : 0), "n"(LINES > 6 ? 0x180 : 0), "n"(LINES > 7 ? 0x1c0 : 0)
+                 : "memory");
 }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids land on
