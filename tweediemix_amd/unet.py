@@ -873,13 +873,15 @@ class UNetPlan:
         self._emit(lib.tmix_timestep_embedding, self.t_dev.data_ptr(), tsin.data_ptr(), B, C0)
         self._emit(lib.tmix_linear_small, tsin.data_ptr(), W["time_embedding.linear_1.weight"].data_ptr(),
                    W["time_embedding.linear_1.bias"].data_ptr(), None, thid.data_ptr(), B, T, C0, 0, 1)
+        # (emb is only ever used as SiLU(emb) -- every ResnetBlock2D applies its nonlinearity first -- so linear_2 stores SiLU(emb) and the stacked
+        # projection below reads it as is: the activation is evaluated 4 x 1280 times per step instead of once per output column, 20,480 x that)
         self._emit(lib.tmix_linear_small, thid.data_ptr(), W["time_embedding.linear_2.weight"].data_ptr(),
-                   W["time_embedding.linear_2.bias"].data_ptr(), self.aug.data_ptr(), emb.data_ptr(), B, T, T, 0, 0)
+                   W["time_embedding.linear_2.bias"].data_ptr(), self.aug.data_ptr(), emb.data_ptr(), B, T, T, 0, 1)
         # every ResnetBlock2D's time_emb_proj(SiLU(emb)) in ONE launch: the weights are stacked along N once per checkpoint
         tw, tb_, starts, names = W.stacked_time_proj()
         tall = torch.empty(B * tw.shape[0], device=self.dev, dtype=F32)
         self.keep.append(tall)
-        self._emit(lib.tmix_linear_small_sections, emb.data_ptr(), tw.data_ptr(), tb_.data_ptr(), tall.data_ptr(), B, tw.shape[0], T, 1,
+        self._emit(lib.tmix_linear_small_sections, emb.data_ptr(), tw.data_ptr(), tb_.data_ptr(), tall.data_ptr(), B, tw.shape[0], T, 0,
                    starts.data_ptr(), len(names))
         hs = starts.tolist()
         self._temb = {n: tall[hs[i] * B:hs[i + 1] * B].view(B, hs[i + 1] - hs[i]) for i, n in enumerate(names)}
