@@ -319,7 +319,7 @@ def test_gemm_rejects_bad_shapes(ops):
 
 
 # --------------------------------------------------------------------------- conv
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 20])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 10, 6, 128, 68), (3, 8, 8, 320, 320)])
 def test_conv3x3(ops, mode, B, H, W, Cin, Cout, cfg):
@@ -449,7 +449,7 @@ def test_gemm_leaves_groupnorm_column_statistics(ops, cfg, M, N, K, res):
     _colstats_close(cs, out)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 5, 7, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 5, 7, 12, 13, 14, 15, 20])
 @pytest.mark.parametrize("mode,B,H,W,Cin,Cout,res", [(0, 2, 16, 16, 64, 320, True), (1, 1, 16, 16, 128, 64, False), (2, 3, 8, 8, 64, 136, False),
                                                       (0, 2, 32, 32, 64, 640, True)])
 def test_conv_leaves_groupnorm_column_statistics(ops, cfg, mode, B, H, W, Cin, Cout, res):

@@ -46,9 +46,11 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     if (conv) {
         // the phase-offset and loader-wave mainloops exist for the plain GEMM only (the im2col gather's per-row offset tables do
         // not fit a loader wave's register budget, and the conv mainloop already runs at 0.8-1.0 PFLOP/s): nearest plain tiling
+        // (tiling 20 -- 128 x 160 plus TWO loader waves -- also exists for the convolution since the kernels are instantiated per epilogue family:
+        // 244 VGPRs, no scratch; not with shortcut taps, whose source switch lives in the staging path of the math waves' kernel)
         if (cfg == 16) cfg = 4;
         else if (cfg == 17) cfg = 2;
-        else if (cfg >= 18) cfg = 12;
+        else if (cfg >= 18 && (cfg != 20 || p.S1)) cfg = 12;
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
     // column statistics (cs_out) are compiled for the lock-step tilings only: the phase-offset ones run as their nearest plain tiling
     if (p.cs_out) { if (cfg == 16) cfg = 4; else if (cfg == 17) cfg = 2; }

@@ -247,7 +247,7 @@ gemm_conv_kernel(const Params p) {
                 const int hw = p.Ho * p.Wo;
 #pragma unroll
                 for (int r = 0; r < RA; ++r) {
-                    int m = m0l + r * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
+                    int m = m0l + slot_a(r) * 8 + lrow; if (m > p.M - 1) m = p.M - 1;      // (the rows of THIS loader's r-th instruction)
                     pb[r] = m / hw; const int rem = m - pb[r] * hw;
                     py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
                 }

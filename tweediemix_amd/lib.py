@@ -24,7 +24,7 @@ TILE_EXCLUSIVE = (13, 14, 15)                                  # one workgroup p
 # compiled into the tilings with registers to spare).  The plan builder applies the same map to the DESCRIPTOR, so the number of
 # row-statistics partials the consumers are told (tmix_gemm_stats_parts) is that of the kernel that really runs.
 F8COPY_TILE_ALT = {6: 4, 8: 7, 9: 2, 10: 1, 11: 4, 14: 12, 19: 12, 20: 12, 21: 12}
-TILE_LW = (19, 20, 21)                                           # loader-wave tilings: GEMM only (a conv launch runs them as tiling 12)
+TILE_LW = (19, 20, 21)                                           # loader-wave tilings: GEMM only, except 20 (a conv launch runs 19 / 21 as tiling 12)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
