@@ -381,19 +381,29 @@ __global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) 
     frag_ab ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    // the queries of BOTH 32-query blocks are requested here, in the same memory round trip as K / V^T: loaded at the top of each block they cost
+    // the second block a round trip of its own, in a kernel whose whole run is a few of them
+    frag_ab qraw[SQW / 32][2][2];
+#pragma unroll
+    for (int blk = 0; blk < SQW / 32; ++blk)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            int q = q0 + blk * 32 + qi * 16 + fr; if (q > p.Sq - 1) q = p.Sq - 1;
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) qraw[blk][qi][ds] = *(const frag_ab*)(Qb + (int64_t)q * p.ldq + ds * 32 + fg * 8);
+        }
     if (prof_on) pt1 = prof_now();
 
-#pragma unroll 1
+#pragma unroll
     for (int blk = 0; blk < SQW / 32; ++blk) {
         const int qb = q0 + blk * 32;
         if (qb >= p.Sq) break;
         frag_ab qf[2][2];
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            int q = qb + qi * 16 + fr; if (q > p.Sq - 1) q = p.Sq - 1;
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) {
-                const frag_ab raw = *(const frag_ab*)(Qb + (int64_t)q * p.ldq + ds * 32 + fg * 8);
+                const frag_ab raw = qraw[blk][qi][ds];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[qi][ds][j] = (__bf16)((float)raw[j] * p.scale_log2e);
             }
