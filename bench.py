@@ -35,8 +35,11 @@ METRIC = "denoise steps/sec @ SDXL 1024^2 K=3 concepts (fusion phase); images/se
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: one trajectory's worth of steps behind ten warm-up steps.  ms_per_step falls with the length of the run on these boxes (same box, same
+    # library: 33.5 ms at 20 steps / 3 warm-up, 33.1 at 40 / 3, 32.7 at 50 / 10, 32.3 at 100 / 10 -- the clocks are still ramping through the first ~2 s of
+    # load; tools/jobs/r3zzx_steps.sh), and a denoising trajectory is 50 steps (75 UNet calls, ~2 s) long
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kind", default="both", choices=["both", "lora", "custom"])
     ap.add_argument("--lora-mode", dest="lora_mode", default="merged", choices=["merged", "lowrank"],
                     help="lowrank: up(down(x)) as the routed projections' last K-tile (tmix_lora_down + shared weights) instead of merged per-concept weight sets")
