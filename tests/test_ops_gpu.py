@@ -631,6 +631,39 @@ def test_gemm_fused_layernorm_pair(ops, cfg):
     close(vt[0, :, :M], z4[:, 2 * C1:].T, rtol=2 ** -6, atol_frac=4e-3)
 
 
+@pytest.mark.parametrize("r", [1, 10, 100, 300, 1000])
+@pytest.mark.parametrize("cfg", [2, 12, 14])
+def test_fused_layernorm_with_row_means_far_from_zero(ops, cfg, r):
+    """the folded LayerNorm takes var = E[x^2] - mean^2 from fp32 partial sums (gemm_kernel.h ln_reduce) and subtracts mean * colsum(W') from an
+    fp32 accumulator: rows with |mean| / std = r lose ~ 2 r^2 * 2^-24 of the variance and r * 2^-24 * sqrt(K) of the products.  Isolated here from
+    the bf16 rounding of the hidden state itself (the reference sees the SAME bf16 rows: an identity producer stores them exactly and leaves the
+    statistics): exact to the bf16 output rounding up to r = 100 (1.7e-3), 2.4e-3 at 300, 3.2e-2 at 1000 -- the bound asserted is max(4e-3, r^2 * 2^-24), and the reason the plan has no
+    two-pass fallback: a bf16 row with r = 100 has already lost 4 of its 8 mantissa bits to the mean before any norm looks at it."""
+    from tweediemix_amd.weights import fold_layernorm
+    M, C1, N2 = 256, 1280, 320
+    z = rnd(M, C1, seed=170).float()
+    x = ((z - z.mean(-1, keepdim=True)) / z.std(-1, keepdim=True) + float(r)).to(BF)      # bf16 rows with mean ~ r, std ~ 1 (coarser for large r)
+    eye = torch.eye(C1, device="cuda", dtype=BF)
+    parts = ops.stats_parts(C1, cfg)
+    stats = torch.full((parts, M, 2), float("nan"), device="cuda")
+    h = ops.gemm(x, eye, row_stats_out=stats, tile_cfg=cfg)
+    assert torch.equal(h, x)
+    gamma = rnd(C1, seed=174, dtype=torch.float32) * 0.2 + 1
+    beta = rnd(C1, seed=175, dtype=torch.float32) * 0.3
+    w2 = rnd(N2, C1, seed=176, scale=C1 ** -0.5)
+    b2 = rnd(N2, seed=177, dtype=torch.float32)
+    wp, cs, t = fold_layernorm(w2, gamma, beta, b2)
+    y = ops.gemm(h, wp, bias=t, ln_stats=stats, ln_colsum=cs, tile_cfg=cfg).double()
+    xd = h.double()
+    mu, var = xd.mean(-1, keepdim=True), xd.var(-1, unbiased=False, keepdim=True)
+    # the reference normalises the same bf16 rows in fp64 and applies the SAME folded bf16 weights (the fold's own rounding is tested above)
+    ref = ((xd - mu) / (var + 1e-5).sqrt()) @ wp.double().T + t.double()
+    err = ((y - ref).norm() / ref.norm()).item()
+    bound = max(4e-3, r * r * 2.0 ** -24)
+    print(f"fused LayerNorm, rows with |mean|/std = {r} (actual std {var.sqrt().mean().item():.3g}), tiling {cfg}: rel-L2 {err:.3e} (bound {bound:.3e})")
+    assert err <= bound, (err, bound)
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 7, 13])
 def test_conv_temporal_3x1x1(ops, cfg):
     """TMIX_CONV_T3 against F.conv3d with a (3,1,1) kernel and (1,0,0) padding (diffusers TemporalConvLayer):

@@ -961,6 +961,46 @@ class UNetPlan:
         self.run()
         return self.eps
 
+    def norm_condition(self, latent, t):
+        """calibration pass: run the forward launch by launch and read, behind every GEMM that leaves LayerNorm row statistics, how far the rows'
+        means sit from zero in units of their standard deviation: [(op index, rows, width, max |mean| / std, median)] per LayerNorm site.
+        What the number means for this plan (DESIGN "hostile statistics"): a bf16 hidden state with |mean| / std = r carries rounding noise of
+        ~ r * 2^-9 of a row's std per element whatever normalises it, and the single-pass fp32 variance of the folded LayerNorm
+        (gemm_kernel.h ln_reduce) a relative error of ~ 2 r^2 * 2^-24 -- smaller than the first for every r a bf16 stream can carry.
+        LN_COND_WARN marks the sites where the STREAM's noise passes 2 % of a row's std."""
+        self.latent.copy_(latent)
+        self.t_dev.fill_(float(t))
+        st = torch.cuda.current_stream().cuda_stream
+        prods = {id(d) for d, _c in self._ln_links}
+        out = []
+        for i, (fn, args) in enumerate(self.ops):
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, fn.__name__)
+            m = self.op_meta.get(i)
+            if not m or m[0] != "gemm" or id(m[2]) not in prods:
+                continue
+            d = m[2]
+            torch.cuda.synchronize()
+            parts = ops.stats_parts(d.N, d.tile_cfg)
+            base = (d.row_stats_out - self._ln_buf.data_ptr()) // 4
+            rows = torch.arange(d.M, device=self.dev)
+            s = torch.zeros(d.batch, d.M, 2, device=self.dev, dtype=torch.float64)
+            for bz in range(d.batch):
+                for q in range(parts):
+                    off = base + bz * d.strideStatsOut + (q * d.ldStatsOut + rows) * 2
+                    s[bz, :, 0] += self._ln_buf[off].double()
+                    s[bz, :, 1] += self._ln_buf[off + 1].double()
+            mean = s[..., 0] / d.N
+            var = (s[..., 1] / d.N - mean * mean).clamp_min(1e-30)
+            r = (mean.abs() / var.sqrt()).flatten()
+            out.append((i, d.M * d.batch, d.N, r.max().item(), r.median().item()))
+        torch.cuda.synchronize()
+        return out
+
+
+LN_COND_WARN = 16.0       # |mean| / std of a LayerNorm row beyond which a bf16 hidden state is itself the problem (its rounding noise > 2 % of the row's std)
+
 
 def refine_group(self, top=14, reps=9, verbose=False, cands=None):
     """second tuning pass, for the chains of a group or for ONE plan (the event-timed eager ranking of UNetPlan.autotune is noisy
