@@ -158,7 +158,9 @@ def parity_check(tw, args, parts, kind, device):
     tol = 1e-1 if tw.fp8 else 2e-2
     assert rel < tol and rel_eps < tol, f"timed path differs from the eager single-chain run: rel L2 latent {rel}, eps {rel_eps}"
     return {"vs": "eager single-chain bf16 run of the same step (no graph, one stream)", "rel_l2": rel_eps, "rel_l2_latent": rel, "tol": tol,
-            "what": "rel_l2 = UNet output eps [K+1,4,h,w]; rel_l2_latent = the updated latent"}
+            "what": "rel_l2 = UNet output eps [K+1,4,h,w]; rel_l2_latent = the updated latent",
+            "kind": "capture sanity check: hipGraph replay vs an eager run of the SAME HIP kernels -- not oracle parity; the timed plan against the "
+                    "fp32 oracle is tests/test_unet_gpu.py::test_headline_size_timed_plan_graph_vs_fp32_oracle (rel-L2 4.5e-3, bound 2e-2)"}
 
 
 # ------------------------------------------------------------------------------------------------ in-situ roofline
@@ -571,8 +573,12 @@ def main(argv=None):
     # the timed plan runs the tilings of the SHIPPED table (nothing re-tuned on this box): the same assertion the oracle parity
     # tests make for the plan they check (tests/test_unet_gpu.py::test_headline_size_timed_plan_graph_vs_fp32_oracle)
     follows, bad = U.tilings_follow_table(plan)
-    assert follows or os.environ.get("TMIX_TUNE_FILE") is not None or args.tiny, f"timed plan deviates from the shipped tile table: {bad[:5]}"
-    tilings = {"used": U.used_tilings(plan), "follow_shipped_table": follows, "table": os.path.basename(U._TUNE_FILE) if U._TUNE_FILE else None}
+    # a launch whose shape the table HOLDS must run the table's tiling (a deviation means something re-tuned it on this box); a shape the table
+    # does not hold (non-default --res / --seeds-per-gpu / --lora-mode lowrank) was timed when the plan was built: reported, not fatal
+    deviating = [b for b in bad if b[2] is not None]
+    assert not deviating or os.environ.get("TMIX_TUNE_FILE") is not None or args.tiny, f"timed plan deviates from the shipped tile table: {deviating[:5]}"
+    tilings = {"used": U.used_tilings(plan), "follow_shipped_table": follows, "shapes_not_in_table": len(bad) - len(deviating),
+               "table": os.path.basename(U._TUNE_FILE) if U._TUNE_FILE else None}
     plan_build_s = time.perf_counter() - t_start - startup_s
     x = torch.randn(S_, 4, tw.h, tw.w, generator=torch.Generator().manual_seed(1000 + rank)).to(device)
     dt, _x = timed_fusion_steps(tw, args, world, device, x)

@@ -126,11 +126,12 @@ def main(argv=None):
         return LA.self_launch(opt.gpus)
     rank, local, world = LA.rank_env()
     if world > 1:
-        import torch.distributed as dist
         single = bool(os.environ.get('TMIX_SINGLE_GPU_DIST_TEST'))      # tests: all ranks on GPU 0, gloo
         opt.device = 'cuda:0' if single else f'cuda:{local}'
         torch.cuda.set_device(torch.device(opt.device))
-        dist.init_process_group('gloo' if single else 'nccl')
+        # through dist.init like bench.py: a rendezvous port stolen between the launcher's probe and the bind exits with EADDRINUSE_RC,
+        # which launch.self_launch retries on a fresh port
+        D.init(torch.device(opt.device), world, backend='gloo' if single else None)
     say = print if rank == 0 else (lambda *a, **k: None)
     if opt.sd_version != 'xl':
         say(f"note: --sd_version {opt.sd_version}: like the reference (fusion_sampling.py:119) only the SDXL pipeline exists")

@@ -92,3 +92,10 @@ def test_argument_errors_are_reported_before_any_launch():
     assert l.tmix_prof_begin(None, 4, 0) < 0 and l.tmix_prof_end() == 0
     d = lib.GemmDesc()
     assert l.tmix_gemm_bf16(C.byref(d), None) < 0 and b"null" in l.tmix_last_error_string()
+    # tmix_gemm_fp8 + col_stats_out: compiled for the bf16 tilings only -- refused, not remapped onto a bf16 kernel over e4m3 bytes
+    d = lib.GemmDesc()
+    d.A, d.W, d.C, d.col_stats_out = 0x1000, 0x2000, 0x3000, 0x4000
+    d.M, d.N, d.K, d.batch, d.lda, d.ldw, d.ldc, d.n_trans_begin = 256, 256, 256, 1, 256, 256, 256, -1
+    assert l.tmix_gemm_fp8(C.byref(d), C.cast(C.c_void_p(0x5000), C.POINTER(C.c_uint8)), C.cast(C.c_void_p(0x6000), C.POINTER(C.c_uint8)), None) == lib.EINVAL
+    assert b"col_stats_out" in l.tmix_last_error_string()
+

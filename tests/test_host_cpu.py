@@ -260,3 +260,23 @@ def test_sidecar_directories_do_not_collide_across_ranks():
     assert len({d for d, _g in dirs}) == 4 and all(d.startswith("out") for d, _g in dirs)
     assert [g for _d, g in dirs] == [0, 1, 2, 3]                    # --seg_gpu 1 is rank 1's GPU: every rank uses its own instead
     assert M.sidecar_layout("out", 2, 4, 2, 6) == ("out/rank2", 6)  # a GPU outside the sampling ranks is honoured
+
+
+def test_sidecar_gpu_is_a_physical_id_when_the_parent_restricts_the_visible_devices(monkeypatch):
+    """the side-car's command line sets CUDA_VISIBLE_DEVICES itself (fusion_sampling.py:458): rank-local GPU i of a job started under
+    HIP_VISIBLE_DEVICES=4,5,6,7 is physical GPU 4 + i."""
+    from tweediemix_amd import masks as M
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert [M.sidecar_layout("out", r, 4, r, 1)[1] for r in range(4)] == [4, 5, 6, 7]
+    assert M.sidecar_layout("out", 1, 4, 1, 9) == ("out/rank1", 9)      # an explicit GPU outside the job is passed through
+    assert M.sidecar_layout("out", 0, 1, 0, 1) == ("out", 1)            # one process: the reference's own arguments
+
+
+def test_gather_without_a_process_group_is_an_error_when_there_are_other_ranks():
+    import pytest
+    import torch
+    from tweediemix_amd import dist as D
+    x = torch.zeros(2, 4, 8, 8)
+    assert D.gather_latents(x, 2, 0, 1) is x
+    with pytest.raises(AssertionError):
+        D.gather_latents(x, 4, 0, 2)

@@ -156,6 +156,7 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
         if (has_trans && aligned16(d->Ct) && (d->ldct % 8) == 0 && (d->strideCt % 8) == 0) p.wide |= 4;
     }
     if (d->col_stats_out) {
+        if (fp8) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: col_stats_out is compiled for the bf16 tilings only (the fp8 loop would be remapped to a bf16 kernel over e4m3 bytes)");
         if (has_trans || d->epilogue != TMIX_EPI_NONE || d->row_stats_out || (d->reserved0 & TMIX_F8_COPY_OUT) || d->batch != 1 || (d->M % TMIX_COLSTATS_ROWS) || (d->N % 8)
             || !aligned16(d->col_stats_out) || !(p.wide & 1))
             TMIX_FAIL(TMIX_EINVAL, "gemm: col_stats_out needs the plain staged bf16 epilogue (16-byte aligned C / residual rows, N %% 8 == 0), batch == 1, M %% 32 == 0, "

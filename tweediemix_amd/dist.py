@@ -19,6 +19,7 @@ def gather_latents(local: torch.Tensor, n_total: int, rank: int, world: int) -> 
     seed order on every rank.  Ragged shards (n_total % world != 0) are padded to the largest shard so a
     single fixed-size all_gather_into_tensor suffices (one ring pass over xGMI, <= 16 MiB for 64 seeds)."""
     if not dist.is_initialized():
+        assert world <= 1, "gather_latents: world > 1 but no process group (dist.init was not called): the other ranks' seeds would be dropped silently"
         return local
     per = (n_total + world - 1) // world
     shape = local.shape[1:]

@@ -86,7 +86,15 @@ def sidecar_layout(output_path, rank: int, world: int, local_gpu: int, seg_gpu: 
     import os
     if world <= 1:
         return output_path, seg_gpu
-    return os.path.join(output_path, f"rank{rank}"), (local_gpu if 0 <= seg_gpu < world else seg_gpu)
+    gpu = local_gpu if 0 <= seg_gpu < world else seg_gpu
+    # the side-car's command line sets CUDA_VISIBLE_DEVICES itself, in PHYSICAL ids: when the parent already restricts the visible devices,
+    # rank-local index i is the i-th entry of the parent's list, not GPU i
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis and gpu == local_gpu:
+        ids = [v.strip() for v in vis.split(",") if v.strip()]
+        if 0 <= local_gpu < len(ids) and ids[local_gpu].lstrip("-").isdigit():
+            gpu = int(ids[local_gpu])
+    return os.path.join(output_path, f"rank{rank}"), gpu
 
 
 class SidecarMaskProvider:

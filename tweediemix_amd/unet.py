@@ -272,7 +272,7 @@ class UNetWeights:
         return self._fp8[ck]
 
     def nbytes(self):
-        return sum(v.numel() * v.element_size() for v in self.t.values())
+        return sum(v.numel() * v.element_size() for v in self.t.values() if torch.is_tensor(v))      # (lowrank keeps the Python int '.lr.P' beside the tensors)
 
 
 # =====================================================================================
