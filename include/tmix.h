@@ -247,6 +247,12 @@ int tmix_conv_out(const void* x_nhwc, const void* w_ohwi, const float* bias, flo
 int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
                   const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
                   int B, int H, int Sq, int Skv, float scale, void* stream);
+/* the same attention with the output as the block-scaled A operand of the out-projection behind it (utils_lora.py:116-119 / utils_custom.py:104-106 on
+ * e4m3 operands, tmix_gemm_fp8 + TMIX_F8_A_BLOCK_SCALES): O8 [B*Sq][ldo8] OCP e4m3 bytes (head h at columns h*64..), scales [H*2][ldScale >= B*Sq] one
+ * E8M0 byte per (row, 32 columns), k-block major -- bit for bit what an MX quantiser makes of the bf16 tensor tmix_attn_fwd writes; no bf16 output. */
+int tmix_attn_fwd_f8(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                     const void* Vt, int64_t ldvt, int64_t strideVt, void* O8, int64_t ldo8, void* scales, int64_t ldScale,
+                     int B, int H, int Sq, int Skv, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisation / small ops (diffusers GroupNorm(32)+SiLU, LayerNorm, Timesteps, time MLPs).

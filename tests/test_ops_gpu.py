@@ -374,6 +374,27 @@ def test_attention(ops, B, H, Sq, Skv):
     close(out, ref.transpose(1, 2).reshape(B, Sq, Cc), rtol=2 ** -6, atol_frac=4e-3)
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv", [(2, 2, 256, 256), (1, 3, 64, 77), (1, 2, 1024, 1024), (4, 5, 128, 77), (2, 1, 200, 80)])
+def test_attention_output_as_e4m3_with_mx_block_scales(ops, B, H, Sq, Skv):
+    """tmix_attn_fwd_f8 (both kernels: the pipelined one and the short-key one): bytes and scales equal a torch MX quantiser applied to the bf16
+    tensor tmix_attn_fwd writes -- so the out-projection behind it reads exactly what a quantiser launch would have produced."""
+    Cc = H * 64
+    q, k, v = rnd(B, Sq, Cc, seed=40), rnd(B, Skv, Cc, seed=41) * 3, rnd(B, Skv, Cc, seed=42)
+    v[:, :, 5] *= 40.0                                         # one loud channel: its 32-column block gets its own scale
+    ld = (Skv + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, ld, device="cuda", dtype=BF)
+    vt[:, :, :Skv] = v.transpose(1, 2)
+    out = ops.attention(q, k, vt, H, Skv, 0.125)
+    cp = ops.F8Copy(B * Sq, Cc, "cuda")
+    cp.buf.fill_(0x5a)
+    ops.attention(q, k, vt, H, Skv, 0.125, f8_out=cp)
+    torch.cuda.synchronize()
+    qq, ss, _deq = _mx_quantize(out.float().view(B * Sq, Cc))
+    assert torch.equal(cp.scales, ss)
+    same = (cp.q == qq) | (((cp.q & 0x7f) == 0) & ((qq & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+
+
 def test_attention_online_softmax_rescale(ops):
     """a late key with a huge score forces the running max to jump in the last tile (guide rule 26)."""
     B, H, Sq, Skv = 1, 1, 128, 256
@@ -731,7 +752,7 @@ def test_fp8_row_quantizer_matches_torch_float8(ops, rows, K):
     assert float((back - xf).abs().max() / xf.abs().max()) < 2 ** -3   # 3 mantissa bits
 
 
-@pytest.mark.parametrize("tile", [0, 16, 17])
+@pytest.mark.parametrize("tile", [0, 12, 16, 17, 21])       # 12 / 21: e4m3 in the lock-step loops (128 x 160 without / with loader waves)
 @pytest.mark.parametrize("M,N,K,kw", [(512, 512, 256, {}), (1024, 1280, 1280, {"bias": True, "residual": True}),
                                       (300, 264, 128, {"bias": True}), (2048, 2560, 1280, {"geglu": True}),
                                       (1024, 3840, 1280, {"trans": True, "batch": 2})])
@@ -786,7 +807,7 @@ def _mx_quantize(x):
                                                                         * torch.exp2(e).unsqueeze(2)).view(rows, K)
 
 
-@pytest.mark.parametrize("tile", [16, 17])
+@pytest.mark.parametrize("tile", [12, 16, 17, 21])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1024, 1280, 5120), (300, 264, 128)])
 def test_gemm_fp8_with_mx_block_scales_on_a(ops, tile, M, N, K):
     """TMIX_F8_A_BLOCK_SCALES: one E8M0 scale per 32 K values of every A row, kept in LDS for the K loop (lane half h of a 64-wide
@@ -859,6 +880,47 @@ def test_gemm_leaves_an_e4m3_copy_of_its_output_for_the_next_gemm(ops, tile, bat
     from tweediemix_amd.lib import TmixError
     with pytest.raises(TmixError):                                      # rows that do not fill 32-row blocks are refused
         ops.gemm(a[:, :150].contiguous(), w, tile_cfg=tile, f8_copy=ops.F8Copy(batch * 150, N, "cuda"))
+
+
+@pytest.mark.parametrize("tile", [12, 21])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_gemm_fp8_lockstep_tilings_leave_copy_and_statistics(ops, tile, batch):
+    """the N = 1280 GEMMs of an fp8 plan (attention out-projections, FF2) on e4m3 operands in the 128 x 160 loops: bf16 rows + residual, LayerNorm row
+    statistics and the e4m3 + MX-block copy of the stored rows from ONE launch (with loader waves: epilogue family 4) -- each against what the
+    phase-offset tiling 17 / a torch MX quantiser produce."""
+    M, N, K = 256, 320, 384
+    a = rnd(batch * M, K, seed=30, dtype=torch.float32)
+    a[:, 32:64] *= 11.0
+    w = rnd(batch, N, K, seed=31, scale=K ** -0.5)
+    a8, sa, ad = _mx_quantize(a)
+    w8, sw = ops.quantize_fp8_rows(w.view(batch * N, K))
+    bias = rnd(N, seed=32, dtype=torch.float32)
+    res = rnd(batch, M, N, seed=33)
+    st = torch.full((ops.stats_parts(N, tile), batch * M, 2), float("nan"), device="cuda")
+    cp = ops.F8Copy(batch * M, N, "cuda")
+    cp.buf.fill_(0x5a)
+    out = ops.gemm_fp8(a8.view(batch, M, K), sa, w8.view(batch, N, K), sw.view(batch, N), bias=bias, residual=res, tile_cfg=tile, a_block_scales=True,
+                       row_stats_out=st, f8_copy=cp)
+    torch.cuda.synchronize()
+    want = torch.einsum("bmk,bnk->bmn", ad.view(batch, M, K), ops.dequantize_fp8_rows(w8, sw).view(batch, N, K)) + bias + res.float()
+    close(out, want)
+    of = out.float().view(batch * M, N)
+    torch.testing.assert_close(st[:, :, 0].sum(0), of.sum(-1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[:, :, 1].sum(0), (of ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+    q, s, _deq = _mx_quantize(of)
+    assert torch.equal(cp.scales, s)
+    same = (cp.q == q) | (((cp.q & 0x7f) == 0) & ((q & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+
+
+def test_gemm_fp8_lockstep_tilings_refuse_the_e4m3_geglu_output(ops):
+    """MX blocks of 32 GEGLU output columns need wave tiles that are multiples of 64 weight rows wide: a 160-wide tile ends inside a block -- refused."""
+    from tweediemix_amd.lib import TmixError
+    a8 = torch.zeros(256, 256, device="cuda", dtype=torch.uint8); sa = torch.zeros(256, device="cuda", dtype=torch.uint8)
+    w8 = torch.zeros(1280, 256, device="cuda", dtype=torch.uint8); sw = torch.zeros(1280, device="cuda", dtype=torch.uint8)
+    c8 = torch.zeros(256, 640, device="cuda", dtype=torch.uint8); cs = torch.zeros(20, 256, device="cuda", dtype=torch.uint8)
+    with pytest.raises(TmixError):
+        ops.gemm_fp8(a8, sa, w8, sw, bias=torch.zeros(1280, device="cuda"), geglu=True, tile_cfg=21, f8_out=(c8, cs))
 
 
 @pytest.mark.parametrize("tile", [16, 17])

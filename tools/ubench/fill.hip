@@ -153,7 +153,7 @@ void run_gather(const char* name, const char* src, float* out, int ld) {
 
 template <int PATH, int NW, int D>
 void run(const char* name, const char* src, float* out, int wgs, int window, int shared) {
-    const int iters = 4096;
+    const int iters = 4096;      // (4 MiB per wave: a 512 KiB window is walked several times)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int smem = NW * D * 1024;
     hipFuncSetAttribute((const void*)k_fill<PATH, NW, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -191,6 +191,11 @@ int main() {
         run<4, 4, 16>("lds-dma + mfma same wave", src, out, 256, window, shared);
         run<4, 4, 32>("lds-dma + mfma same wave", src, out, 256, window, shared);
     }
+    // beyond the L2s: 128 MB in total (Infinity Cache resident after the warm-up pass), nothing shared -- what the fabric delivers to 256 streaming CUs
+    run<0, 8, 16>("lds-dma, 512 KiB windows (MALL)", src, out, 256, 512 * 1024, 0);
+    run<1, 8, 16>("global->vgpr, 512 KiB windows (MALL)", src, out, 256, 512 * 1024, 0);
+    run<0, 4, 32>("lds-dma, 512 KiB windows (MALL)", src, out, 256, 512 * 1024, 0);
+    run<0, 4, 32>("lds-dma, 1 MiB windows (HBM+MALL)", src, out, 256, 1024 * 1024, 0);
     // fewer CUs active: is the limit per CU or per chip / XCD?
     run<0, 4, 32>("lds-dma, 64 WGs", src, out, 64, 64 * 1024, 0);
     run<0, 4, 32>("lds-dma, 128 WGs", src, out, 128, 64 * 1024, 0);

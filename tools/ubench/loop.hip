@@ -14,14 +14,25 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 constexpr int PIECES = 36;           // 1 KiB pieces per K-tile
 constexpr int NSLOT = 4;             // ring slots of 36 KiB
 
-template <int MODE, int NL, int D, int BAR, int RD, int MF>
+// REAL = 1: the footprint of the real launch -- A [4096 x ld] and W [1280 x ld] row-major, workgroup -> (tile_m, tile_n) by the GEMM kernel's XCD-aware
+// grouping (8 A tiles x 4 W tiles per XCD), K walked once per repetition (ld / 128 K-tiles), `reps` repetitions: the lab's "hot" state.
+template <int MODE, int NL, int D, int BAR, int RD, int MF, int REAL = 0>
 __global__ void __launch_bounds__((4 + NL) * 64) k_loop(const char* src, float* out, int ktiles, int ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int region = (blockIdx.x & 7) * 4 + ((blockIdx.x >> 3) & 3);
     const char* base = src + (size_t)region * 288 * ld;          // 288 operand rows (A 128 + W 160) of this workgroup, shared inside the XCD
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 288 * ld, 0x00020000);
-    const unsigned voff = (lane >> 3) * ld + (((lane & 7) ^ (lane >> 3)) * 16);
+    unsigned radd_a = 0, radd_w = 0;                              // REAL: row offsets of this workgroup's A / W tile inside one [4096 + 1280] x ld matrix
+    if (REAL) {
+        const int id = (blockIdx.x & 7) * 32 + (blockIdx.x >> 3), grp = id >> 6, rem = id & 63;
+        const int tile_n = rem >> 3, tile_m = grp * 8 + (rem & 7);
+        base = src;
+        radd_a = (unsigned)(tile_m * 128) * (unsigned)ld;
+        radd_w = (unsigned)(4096 + tile_n * 160 - 128) * (unsigned)ld;      // pieces 16.. are W rows (piece * 8 - 128)
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, REAL ? (4096 + 1280) * ld : 288 * ld, 0x00020000);
+    const unsigned voff0 = (lane >> 3) * ld + (((lane & 7) ^ (lane >> 3)) * 16);
+    auto pv = [&](int piece) { return voff0 + (unsigned)(piece * 8) * ld + (REAL ? (piece < 16 ? radd_a : radd_w) : 0u); };
     constexpr int NST = NL ? NL : 4;                 // staging waves
     constexpr int PPW = PIECES / NST;                // pieces per staging wave and K-tile
     const bool loader = NL && w >= 4;
@@ -37,7 +48,7 @@ __global__ void __launch_bounds__((4 + NL) * 64) k_loop(const char* src, float* 
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int pc = d % PPW, kt = d / PPW;
-                v[d] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)((pc * NST + sid) * 8) * ld, (unsigned)(kt * 128) % (unsigned)ld, 0));
+                v[d] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, pv(pc * NST + sid), (unsigned)(kt * 128) % (unsigned)ld, 0));
             }
         }
         constexpr int G = MODE == 1 ? D / PPW : 1;       // K-tiles in flight (register sets)
@@ -48,14 +59,14 @@ __global__ void __launch_bounds__((4 + NL) * 64) k_loop(const char* src, float* 
                 char* slot = smem + ((kt + g) % NSLOT) * PIECES * 1024;
                 if (MODE == 0) {
 #pragma unroll
-                    for (int pc = 0; pc < PPW; ++pc) blds16(rs, voff + (unsigned)((pc * NST + sid) * 8) * ld, (unsigned)((kt + g) * 128) % (unsigned)ld, slot + (pc * NST + sid) * 1024);
+                    for (int pc = 0; pc < PPW; ++pc) blds16(rs, pv(pc * NST + sid), (unsigned)((kt + g) * 128) % (unsigned)ld, slot + (pc * NST + sid) * 1024);
                     wait_vmcnt<PPW * 2>();              // two K-tiles stay in flight
                 } else if (MODE == 1) {
 #pragma unroll
                     for (int pc = 0; pc < PPW; ++pc) {
                         wait_vmcnt<D - 1>();
                         *(float4*)(slot + (pc * NST + sid) * 1024 + lane * 16) = v[g * PPW + pc];
-                        v[g * PPW + pc] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)((pc * NST + sid) * 8) * ld, (unsigned)((kt + g + G) * 128) % (unsigned)ld, 0));
+                        v[g * PPW + pc] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, pv(pc * NST + sid), (unsigned)((kt + g + G) * 128) % (unsigned)ld, 0));
                     }
                 }
                 if (BAR) __builtin_amdgcn_s_barrier();
@@ -92,10 +103,10 @@ __global__ void __launch_bounds__((4 + NL) * 64) k_loop(const char* src, float* 
                 if (NL == 0) {
                     const int q = kk * 5 + j;
                     if (q < 9) {
-                        if (MODE == 0) blds16(rs, voff + (unsigned)((q * 4 + w) * 8) * ld, (unsigned)((kt + 2) * 128) % (unsigned)ld, nslot + (q * 4 + w) * 1024);
+                        if (MODE == 0) blds16(rs, pv(q * 4 + w), (unsigned)((kt + 2) * 128) % (unsigned)ld, nslot + (q * 4 + w) * 1024);
                         else {
                             *(float4*)(nslot + (q * 4 + w) * 1024 + lane * 16) = v[q];
-                            v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)((q * 4 + w) * 8) * ld, (unsigned)((kt + 3) * 128) % (unsigned)ld, 0));
+                            v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, pv(q * 4 + w), (unsigned)((kt + 3) * 128) % (unsigned)ld, 0));
                         }
                     }
                 }
@@ -112,19 +123,27 @@ __global__ void __launch_bounds__((4 + NL) * 64) k_loop(const char* src, float* 
     out[blockIdx.x * blockDim.x + tid] = s + (float)fa[0] + v[0].x;
 }
 
-template <int MODE, int NL, int D, int BAR, int RD, int MF>
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float f = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f);
+        p[i] = (unsigned short)(__float_as_uint(f) >> 16);
+    }
+}
+
+template <int MODE, int NL, int D, int BAR, int RD, int MF, int REAL = 0>
 void run(const char* name, const char* src, float* out, int ld) {
     const int ktiles = 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int smem = NSLOT * PIECES * 1024;
-    auto k = k_loop<MODE, NL, D, BAR, RD, MF>;
+    auto k = k_loop<MODE, NL, D, BAR, RD, MF, REAL>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     k<<<256, (4 + NL) * 64, smem>>>(src, out, 50, ld);
     hipEventRecord(e0);
     k<<<256, (4 + NL) * 64, smem>>>(src, out, ktiles, ld);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-26s loaders=%d D=%2d bar=%d reads=%d mfma=%d: %7.1f ns per K-tile  (%5.1f B/clk/CU@2.4GHz; MFMA alone = 267 ns @2.4GHz)\n", name, NL, D, BAR, RD, MF,
+    printf("%-26s %s ld=%5d loaders=%d D=%2d bar=%d reads=%d mfma=%d: %7.1f ns per K-tile  (%5.1f B/clk/CU@2.4GHz; MFMA alone = 267 ns @2.4GHz)\n", name, REAL ? "REAL" : "syn ", ld, NL, D, BAR, RD, MF,
            ms * 1e6 / ktiles, 36864.0 / (ms * 1e6 / ktiles * 2.4));
 }
 
@@ -157,5 +176,19 @@ int main() {
     run<1, 4, 18, 1, 1, 0>("reg-staged loaders", src, out, ld);
     run<1, 4, 18, 1, 0, 0>("reg-staged loaders", src, out, ld);
     run<0, 4, 9, 1, 0, 0>("lds-dma loaders", src, out, ld);
+    // the real launch's footprint (A 4096 x K, W 1280 x K, XCD-grouped tiles), first on the memset operands, then on random bf16 in [-1, 1)
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        if (rnd) { fill_bf16<<<2048, 256>>>((unsigned short*)src, (size_t)128 * 1024 * 1024, 7u); hipDeviceSynchronize(); printf("-- random operands\n"); }
+        for (int l : {10240, 2560}) {
+            run<0, 4, 9, 1, 1, 1, 1>("lds-dma loaders", src, out, l);
+            run<0, 4, 9, 1, 0, 1, 1>("lds-dma loaders", src, out, l);
+            run<0, 4, 9, 1, 1, 0, 1>("lds-dma loaders", src, out, l);
+            run<0, 4, 9, 1, 0, 0, 1>("lds-dma loaders", src, out, l);
+            run<0, 0, 9, 1, 1, 1, 1>("lds-dma by math waves", src, out, l);
+            run<1, 4, 27, 1, 1, 1, 1>("reg-staged loaders", src, out, l);
+        }
+        run<0, 4, 9, 1, 1, 1, 0>("lds-dma loaders", src, out, 2560);
+        run<2, 4, 9, 1, 1, 1, 0>("no staging: reads + mfma", src, out, 2560);
+    }
     return 0;
 }

@@ -43,6 +43,9 @@ struct AttnParams {
     int B, H, Sq, Skv, nq;
     float scale_log2e;
     unsigned long long* prof; int prof_detail;   // in-situ timing slot (common.h) or NULL
+    // tmix_attn_fwd_f8: the output leaves as e4m3 bytes [B*Sq][ldo8] with one E8M0 scale per (row, 32 columns) in the k-block-major form
+    // [C/32][ldSc] -- the block-scaled A operand of the out-projection (tmix_gemm_fp8, TMIX_F8_A_BLOCK_SCALES); O is not written then
+    unsigned char* O8; int64_t ldo8; unsigned char* Sc; int64_t ldSc;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
@@ -69,6 +72,31 @@ __device__ __forceinline__ float xor16_sum(float x) {
 __device__ __forceinline__ float xor32_sum(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// one query row of a head (64 columns over the four lanes fg = 0..3 of a 16-lane row block: lane holds columns df * 16 + fg * 4 .. + 3, df = 0..3)
+// as e4m3 with one scale per 32 columns: what a torch MX quantiser makes of the bf16-rounded row (the values are rounded to bf16 first, so the
+// bytes equal a quantiser pass over the bf16 tensor the plain kernel would have written)
+__device__ __forceinline__ void store_row_f8(const AttnParams& p, int64_t row, int h, int fg, const float (&v)[4][4], bool ok) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        float f[8], am = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            f[k] = (float)(__bf16)v[2 * blk + (k >> 2)][k & 3];
+            am = fmaxf(am, fabsf(f[k]));
+        }
+        am = xor16_max(am); am = xor32_max(am);
+        const int e = e8m0_for_amax(am);
+        const float inv = exp2_neg_int(e);
+        int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
+        int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, q1, true);
+        if (ok) {
+            unsigned char* dst = p.O8 + row * p.ldo8 + h * 64 + blk * 32 + fg * 4;
+            *(int*)dst = q0; *(int*)(dst + 16) = q1;
+            if (fg == 0) p.Sc[(int64_t)(h * 2 + blk) * p.ldSc + row] = (unsigned char)(e + 127);
+        }
+    }
 }
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
@@ -311,6 +339,21 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
     }
 
     if (prof_on) pt2 = prof_now();
+    if (p.O8) {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int q = q0 + qi * 16 + fr;
+            const float inv = 1.0f / lacc[qi][0];
+            float v[4][4];
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[df][r] = o[df][qi][r] * inv;
+            store_row_f8(p, (int64_t)b * p.Sq + min(q, p.Sq - 1), h, fg, v, q < p.Sq);
+        }
+        if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2);
+        return;
+    }
     bf16_t* Ob = p.O + (int64_t)b * p.strideO + h * 64;
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
@@ -461,8 +504,17 @@ __global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) 
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int q = qb + qi * 16 + fr;
-            if (q >= p.Sq) continue;
             const float inv = 1.0f / lacc[qi][0];
+            if (p.O8) {                                    // wave-uniform
+                float v[4][4];
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[df][r] = o[df][qi][r] * inv;
+                store_row_f8(p, (int64_t)b * p.Sq + min(q, p.Sq - 1), h, fg, v, q < p.Sq);
+                continue;
+            }
+            if (q >= p.Sq) continue;
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
                 uint2 v;
@@ -477,10 +529,16 @@ __global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) 
 
 }  // namespace
 
-extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
-                             const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
-                             int B, int H, int Sq, int Skv, float scale, void* stream) {
-    if (!Q || !K || !Vt || !O) TMIX_FAIL(TMIX_EINVAL, "attn: null pointer");
+static int attn_entry(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                      const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                      void* O8, int64_t ldo8, void* Sc, int64_t ldSc,
+                      int B, int H, int Sq, int Skv, float scale, void* stream) {
+    if (!Q || !K || !Vt || (!O && !O8)) TMIX_FAIL(TMIX_EINVAL, "attn: null pointer");
+    if (O8) {
+        if (!Sc || (ldo8 % 4) || ldo8 < (int64_t)H * 64 || ldSc < (int64_t)B * Sq || (((uintptr_t)O8) & 3))
+            TMIX_FAIL(TMIX_EINVAL, "attn_f8: needs the scale array [H*2][ldSc >= B*Sq] and 4-byte aligned e4m3 rows of ldo8 >= H*64 bytes");
+        O = (void*)Q; ldo = 4; strideO = 4;        // (the bf16-output checks below do not apply; p.O is never written)
+    }
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) TMIX_FAIL(TMIX_ESHAPE, "attn: empty problem B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
     if ((int64_t)Skv * ldk >= (1ll << 31) || 64 * ldvt >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "attn: per-head K/V extent exceeds 32-bit offsets");
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (strideQ % 8) || (strideK % 8) || (strideVt % 8) || (strideO % 4))
@@ -498,6 +556,7 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     p.K = (const bf16_t*)K; p.ldk = ldk; p.strideK = strideK;
     p.Vt = (const bf16_t*)Vt; p.ldvt = ldvt; p.strideVt = strideVt;
     p.O = (bf16_t*)O; p.ldo = ldo; p.strideO = strideO;
+    p.O8 = (unsigned char*)O8; p.ldo8 = ldo8; p.Sc = (unsigned char*)Sc; p.ldSc = ldSc;
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.prof = tmix_prof_take(&p.prof_detail);
@@ -519,4 +578,17 @@ extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const 
     attn_fwd_pipe_kernel<<<dim3((unsigned)nwg), 256, SMEM_P, (hipStream_t)stream>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
+}
+
+extern "C" int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                             const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                             int B, int H, int Sq, int Skv, float scale, void* stream) {
+    return attn_entry(Q, ldq, strideQ, K, ldk, strideK, Vt, ldvt, strideVt, O, ldo, strideO, nullptr, 0, nullptr, 0, B, H, Sq, Skv, scale, stream);
+}
+
+extern "C" int tmix_attn_fwd_f8(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                                const void* Vt, int64_t ldvt, int64_t strideVt, void* O8, int64_t ldo8, void* scales, int64_t ldScale,
+                                int B, int H, int Sq, int Skv, float scale, void* stream) {
+    if (!O8) TMIX_FAIL(TMIX_EINVAL, "attn_f8: null output");
+    return attn_entry(Q, ldq, strideQ, K, ldk, strideK, Vt, ldvt, strideVt, nullptr, 0, 0, O8, ldo8, scales, ldScale, B, H, Sq, Skv, scale, stream);
 }

@@ -31,12 +31,24 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12};
         // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
         if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
-        cfg = alt[cfg];
+        if (!(cfg == 21 && !conv && p.scaleA && p.K % 128 == 0)) cfg = alt[cfg];      // (tiling 21 on e4m3 operands carries the copy itself)
     }
     int f8 = 0;
     if (!conv && p.scaleA) {     // fp8 operands (tmix_gemm_fp8): the phase-offset loop only; 256x128 tiles for narrow N
         f8 = p.ldScaleA ? 2 : 1;
         const int asked = cfg;
+        // the lock-step loops on e4m3 operands (128 x 160 with / without loader waves, 256 x 320): rows of 128 K values
+        // (not for the e4m3 GEGLU output: its MX blocks of 32 output columns need wave tiles that are multiples of 64 weight rows wide -- the
+        // phase-offset tilings' 128 x 64; a 160-wide tile ends in the middle of a block)
+        if ((cfg == 12 || cfg == 21) && p.K % 128 == 0 && !p.f8out) {
+            f8 += 2;
+            // the loader-wave instantiation at the 256-register limit of two waves per SIMD holds the staged plain / GEGLU epilogues only (the transposed and
+            // narrow forms spill there, and scratch traffic would break the counted vmcnt): those launches run without loader waves
+            const bool staged = p.n_trans_begin < 0 && (p.epilogue == TMIX_EPI_GEGLU ? (p.wide & 2) : (p.wide & 1));
+            if (cfg == 21 && !staged) cfg = 12;
+            // ... and the e4m3 copy of C in its straight-line form only (epilogue family 4: bf16 output, no activation, no row-group bias)
+            if (cfg == 21 && p.f8copy && (p.epilogue != TMIX_EPI_NONE || p.rgb)) cfg = 12;
+        } else
         cfg = (cfg == 17 || (cfg != 16 && (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch < 160)) ? 17 : 16;
         if (f8 == 2 && cfg == 16 && p.K / 32 > f8_block_cap(256)) cfg = 17;    // the tile's block scales stay in LDS beside the ring
         // the consumers of row_stats_out were told the partial count of the REQUESTED tiling (tmix_gemm_stats_parts): never change the width under them
@@ -54,11 +66,12 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
     // column statistics (cs_out) are compiled for the lock-step tilings only: the phase-offset ones run as their nearest plain tiling
     if (p.cs_out) { if (cfg == 16) cfg = 4; else if (cfg == 17) cfg = 2; }
-    int rc = launch_group0(cfg, conv, f8, p, batch, st);
-    if (rc == -999) rc = launch_group1(cfg, conv, f8, p, batch, st);
-    if (rc == -999) rc = launch_group2(cfg, conv, f8, p, batch, st);
-    if (rc == -999) rc = launch_group3(cfg, conv, f8, p, batch, st);
+    int rc = f8 >= 3 ? -999 : launch_group0(cfg, conv, f8, p, batch, st);
+    if (rc == -999 && f8 < 3) rc = launch_group1(cfg, conv, f8, p, batch, st);
+    if (rc == -999 && f8 < 3) rc = launch_group2(cfg, conv, f8, p, batch, st);
+    if (rc == -999 && f8 < 3) rc = launch_group3(cfg, conv, f8, p, batch, st);
     if (rc == -999) rc = launch_group4(cfg, conv, f8, p, batch, st);
+    if (rc == -999) rc = launch_group5(cfg, conv, f8, p, batch, st);
     if (rc == -999) TMIX_FAIL(TMIX_EINVAL, "gemm: no kernel for tile_cfg %d", cfg);
     return rc;
 }
@@ -116,12 +129,14 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     p.bytesA = (unsigned)(((int64_t)(d->M - 1) * d->lda + d->K) * el);
     p.bytesW = (unsigned)(((int64_t)(d->N - 1) * d->ldw + d->K) * el);
     if (fp8) {
-        if (d->tile_cfg != TMIX_TILE_AUTO && d->tile_cfg != 16 && d->tile_cfg != 17) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg must be AUTO, 16 (256x256) or 17 (256x128)");
+        const bool lockstep = (d->tile_cfg == 12 || d->tile_cfg == 21) && d->K % 128 == 0 && !(d->reserved0 & TMIX_F8_GEGLU_OUT);
+        if (d->tile_cfg != TMIX_TILE_AUTO && d->tile_cfg != 16 && d->tile_cfg != 17 && !lockstep)
+            TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg must be AUTO, 16 (256x256), 17 (256x128) or -- K %% 128 == 0, no e4m3 GEGLU output -- 12 / 21 (128x160 without / with loader waves)");
         p.scaleA = scaleA; p.scaleW = scaleW; p.strideScaleA = d->strideA ? d->M : 0; p.strideScaleW = d->strideW ? d->N : 0;
         if (d->reserved0 & TMIX_F8_A_BLOCK_SCALES) {
             p.ldScaleA = (int64_t)d->batch * d->M;                                                // [K/32][batch * M], dense
             if ((d->M % 4) || (((uintptr_t)scaleA) & 3)) TMIX_FAIL(TMIX_EALIGN, "gemm_fp8: block-scaled A needs M %% 4 == 0 and a 4-byte aligned scale array");
-            if (d->K / 32 > f8_block_cap(128)) TMIX_FAIL(TMIX_ESHAPE, "gemm_fp8: block-scaled A supports K <= %d", 32 * f8_block_cap(128));
+            if (!lockstep && d->K / 32 > f8_block_cap(128)) TMIX_FAIL(TMIX_ESHAPE, "gemm_fp8: block-scaled A supports K <= %d", 32 * f8_block_cap(128));
             if ((int64_t)(d->K / 32) * p.ldScaleA >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm_fp8: block scale array exceeds 32-bit offsets");
         }
         if (d->reserved0 & TMIX_F8_GEGLU_OUT) {

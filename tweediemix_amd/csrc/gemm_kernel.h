@@ -140,31 +140,45 @@ template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH =
 // waves on one SIMD -- 2 x 5 or 1 x 9 waves per CU -- so those variants must fit 512/3 registers)
 __global__ void __launch_bounds__((WM * WN * KS + LW) * 64, LW ? (NS * (BM + BN) * 128 > 80 * 1024 ? 2 : 3) : (KS == 1 && WM * WN == 4 && NS * (BM + BN) * 128 > 80 * 1024) ? 1 : 2)
 gemm_conv_kernel(const Params p) {
-    static_assert(!PH || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
+    // PH = 4 / 5: fp8 operands (per-row / MX-block A scales, as PH = 2 / 3) in the LOCK-STEP loops below -- every non-phase tiling, loader waves included:
+    // a staged row is still 128 bytes, i.e. 128 K values = TWO v_mfma_scale_f32_32x32x64_f8f6f4 k-steps per K-tile instead of four bf16 ones.  The loops
+    // of this path are bound by operand bytes (tools/ubench/loop.hip with the launch's real footprint: 0.41 us per 36 KB K-tile for the memory system
+    // alone, 0.45 us for MFMAs + fragment reads alone, 0.56 us together) -- e4m3 halves both.  MX-block A scales (PH = 5) ride in the ring: one more
+    // LDS-DMA piece per K-tile, 4 blocks x BM rows of E8M0 bytes behind the W tile of the stage.
+    constexpr bool PHL = PH >= 1 && PH <= 3;           // the phase-offset loop
+    static_assert(!PHL || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
+    static_assert(PH <= 3 || (!CONV && KS == 1), "fp8 lock-step loop: plain GEMM");
     static_assert(KS == 1 || (KS == 2 && !LW && !PH && !CONV), "in-workgroup split-K geometry");
     static_assert(!SC || (CONV && !LW), "shortcut taps belong to the convolution");
     // PH = 2: the same loop on OCP fp8 (e4m3) operands: a slice row is still 64 bytes, i.e. 64 K values, and the eight
     // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
     // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
     // scales once and the K assignment inside a 64-byte slice need only be the same for both operands.
-    constexpr bool F8C = !CONV && !LW && (BM / WM / 32) * (BN / WN / 32) <= 8;     // tilings that can also leave the e4m3 copy of C (register budget)
+    // tilings that can also leave the e4m3 copy of C (register budget): no loader waves -- except the fp8 lock-step kernels, whose W fragments are
+    // single-buffered (ROLL) to make room: every N = 1280 GEMM of an fp8 plan writes that copy, and it is the loader waves that make those launches fast
+    // (as their own epilogue family EK = 4 -- the straight-line staged plain form WITH the copy and nothing else: inside the common family the loader-wave
+    // kernel, at the 256-register limit of two waves per SIMD, spilled 5 dwords)
+    constexpr bool F8C = !CONV && (LW ? (PH >= 4 && EK == 4) : true) && (BM / WM / 32) * (BN / WN / 32) <= 8;
     constexpr bool F8 = PH >= 2;
-    constexpr bool F8B = PH == 3;                      // A carries one scale per 32 K values (MX blocks), streamed with the slices
+    constexpr bool F8B = PH == 3 || PH == 5;           // A carries one scale per 32 K values (MX blocks), streamed with the slices
+    constexpr bool F8L = PH >= 4;                      // fp8 in the lock-step loops
+    constexpr int SCP = (F8L && F8B) ? 1 : 0;          // one scale piece (1 KB slot, 4 * BM bytes used) per stage
     constexpr int EB = F8 ? 1 : 2;                     // bytes per operand element
     constexpr int NW = WM * WN;                        // math waves
     constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
     constexpr int FM = TM / 32, FN = TN / 32;          // 32x32 fragments per wave
-    constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE;
+    constexpr int A_TILE = BM * 128, B_TILE = BN * 128, STAGE = A_TILE + B_TILE + SCP * 1024;
+    static_assert(!SCP || 4 * BM <= 1024, "scale piece");
     constexpr int SLOT = (BM + BN) * 64;               // PH: one 32-wide K slice of both operands (rows of 64 bytes)
-    constexpr int RING = PH ? 4 * SLOT : NS * STAGE;   // bytes of the staging ring (the fused-LayerNorm block sits behind it)
+    constexpr int RING = PHL ? 4 * SLOT : NS * STAGE;   // bytes of the staging ring (the fused-LayerNorm block sits behind it)
     constexpr int SW = LW ? LW : NW * KS;              // waves that share the staging of a K-tile (LW: the loader waves)
     constexpr int IA = BM / 8, IB = BN / 8;            // LDS-DMA instructions per stage (8 rows of 128 bytes each)
     // ... per staging wave; when the waves do not divide them (64x160 over 5 waves) a surplus slot re-stages the last rows
     // (same bytes to the same place), so every wave issues the same count and the counted vmcnt waits stay valid
     constexpr int RA = (IA + SW - 1) / SW, RB = (IB + SW - 1) / SW;
-    constexpr int L = RA + RB;
+    constexpr int L = RA + RB + SCP;                   // (every staging wave issues its share of the scale piece as one exec-masked instruction)
     static_assert(RA >= 1 && RB >= 1 && FM >= 1 && FN >= 1, "tile/wave geometry");
-    static_assert(PH || (NS - 2) * L <= 63, "vmcnt immediate");
+    static_assert(PHL || (NS - 2) * L <= 63, "vmcnt immediate");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifndef TMIX_NO_KERNARG_TOUCH
@@ -236,12 +250,12 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const int par = (LW >= 2) ? (sw_id & 1) : pp;   // two / four loaders: instruction parity = loader id & 1 (both slots hold it)
-                const unsigned sw = ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 8;
+                const unsigned sw = ((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 8;        // swizzled source chunk, in bf16 elements (x 2 = bytes)
                 swp[pp] = sw;
-                woffp[pp] = ((unsigned)(n0l + par * 8 + lrow) * (unsigned)p.ldw + sw) * 2u;
-                wmaxp[pp] = ((unsigned)(p.N - 1) * (unsigned)p.ldw + sw) * 2u;
-                aoffp[pp] = ((unsigned)(m0l + par * 8 + lrow) * (unsigned)p.lda + sw) * 2u;
-                amaxp[pp] = ((unsigned)(p.M - 1) * (unsigned)p.lda + sw) * 2u;
+                woffp[pp] = (unsigned)(n0l + par * 8 + lrow) * (unsigned)p.ldw * (unsigned)EB + sw * 2u;
+                wmaxp[pp] = (unsigned)(p.N - 1) * (unsigned)p.ldw * (unsigned)EB + sw * 2u;
+                aoffp[pp] = (unsigned)(m0l + par * 8 + lrow) * (unsigned)p.lda * (unsigned)EB + sw * 2u;
+                amaxp[pp] = (unsigned)(p.M - 1) * (unsigned)p.lda * (unsigned)EB + sw * 2u;
             }
             if constexpr (CONV) {
                 const int hw = p.Ho * p.Wo;
@@ -254,13 +268,13 @@ gemm_conv_kernel(const Params p) {
             }
         }
     } else
-    if (stager && !PH) {
+    if (stager && !PHL) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int idx = slot_w(r);
         const int sw = ((lane & 7) ^ ((4 * idx + (lane >> 4)) & 7)) * 8;    // swizzled source chunk (elements)
         int n = n0l + idx * 8 + lrow; if (n > p.N - 1) n = p.N - 1;
-        woff[r] = ((unsigned)n * (unsigned)p.ldw + sw) * 2u;
+        woff[r] = (unsigned)n * (unsigned)p.ldw * (unsigned)EB + (unsigned)sw * 2u;
     }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
@@ -274,7 +288,7 @@ gemm_conv_kernel(const Params p) {
             py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
             aoff[r] = 0;
         } else {
-            aoff[r] = ((unsigned)m * (unsigned)p.lda + sw) * 2u;
+            aoff[r] = (unsigned)m * (unsigned)p.lda * (unsigned)EB + (unsigned)sw * 2u;
         }
     }
     }
@@ -282,9 +296,9 @@ gemm_conv_kernel(const Params p) {
     // ---- PH: a slice is (BM + BN) rows of 64 bytes; one LDS-DMA instruction covers 16 rows (lane -> row lane >> 2,
     // 16-byte position lane & 3), and position q of row r holds source chunk q ^ ((r >> 2) & 3): the 16-lane service
     // groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then touch 16 distinct 16-byte bank groups.
-    constexpr int PA = PH ? BM / 16 / NW : 1, PB = PH ? BN / 16 / NW : 1;      // DMA instructions per wave per slice
+    constexpr int PA = PHL ? BM / 16 / NW : 1, PB = PHL ? BN / 16 / NW : 1;      // DMA instructions per wave per slice
     unsigned phA[PA], phW[PB];
-    if constexpr (PH) {
+    if constexpr (PHL) {
         const unsigned ch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * (16 / EB));  // swizzled source chunk (elements)
 #pragma unroll
         for (int r = 0; r < PA; ++r) {
@@ -306,7 +320,7 @@ gemm_conv_kernel(const Params p) {
         for (int r = 0; r < PB; ++r) blds16(rsW, phW[r], (unsigned)s * 64u, sW + (r * NW + w) * 1024);
     };
 
-    const int nk = p.K / BK;
+    const int nk = p.K / (F8L ? 2 * BK : BK);          // (fp8: a staged row of 128 bytes holds 128 K values)
     int tap = 0, cc = 0;                              // conv K-tile cursor: tap (0..8), 64-channel chunk
     int cpt = CONV ? p.Cin / BK : 1;                  // (SC: the chunks of the CURRENT tap -- the shortcut taps 9 / 10 have their own channel counts)
     const int ntaps_all = SC ? p.ntaps + (p.c1s > 0) + (p.c2s > 0) : p.ntaps;
@@ -341,6 +355,27 @@ gemm_conv_kernel(const Params p) {
     };
     if constexpr (CONV) { if (stager) conv_tap_offsets(); }
 
+    // fp8 lock-step loop with MX-block A scales: the K-tile's 4 blocks x BM rows of E8M0 bytes as one 1 KB piece behind the W tile -- lane l carries bytes
+    // [16 l, 16 l + 16) of it (block 16 l / BM, rows 16 l % BM ..), and staging wave s issues the lanes l % SW == s: one exec-masked instruction per wave,
+    // so every staging wave issues the same L instructions per stage (counted vmcnt)
+    const bool sc_mine = SCP && (lane % SW == sw_id) && (16 * lane < 4 * BM);
+    unsigned sc_voff = 0;
+    __amdgpu_buffer_rsrc_t rsSc = rsA;
+    if constexpr (SCP) {
+        rsSc = __builtin_amdgcn_make_buffer_rsrc((void*)p.scaleA, 0, (int)((int64_t)(p.K / 32) * p.ldScaleA), 0x00020000);
+        sc_voff = (unsigned)((16 * lane) / BM) * (unsigned)p.ldScaleA + (unsigned)((16 * lane) % BM) + (unsigned)(bz * p.strideScaleA + m0l);
+    }
+    auto scale_piece = [&](char* sA, int kt) __attribute__((always_inline)) {
+        if constexpr (SCP) { if (sc_mine) blds16(rsSc, sc_voff, (unsigned)kt * 4u * (unsigned)p.ldScaleA, sA + A_TILE + B_TILE); }
+    };
+    // piece r of this wave's share of K-tile kt (plain GEMM without loader waves): A pieces, W pieces, then the scale piece
+    auto dma_piece = [&](const int r, char* sA, int kt) __attribute__((always_inline)) {
+        if constexpr (!CONV && !LW) {
+            if (r < RA) blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
+            else if (r < RA + RB) blds16(rsW, woff[r - RA], (unsigned)kt * (BK * 2), sA + A_TILE + slot_w(r - RA) * 1024);
+            else scale_piece(sA, kt);
+        }
+    };
     auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         char* sA = smem + buf * STAGE;
         char* sW = sA + A_TILE;
@@ -360,16 +395,17 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             if constexpr (CONV) blds16(rsA, cvo[r], (unsigned)cc * (BK * 2), sA + slot_a(r) * 1024);
-            else if constexpr (LW) blds16(rsA, min(aoffp[(r * LW) & 1] + (unsigned)(slot_a(r) >> 1) * (unsigned)(32 * p.lda), amaxp[(r * LW) & 1]),
+            else if constexpr (LW) blds16(rsA, min(aoffp[(r * LW) & 1] + (unsigned)(slot_a(r) >> 1) * (unsigned)(16 * EB * p.lda), amaxp[(r * LW) & 1]),
                                           (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
             else                blds16(rsA, aoff[r], (unsigned)kt * (BK * 2), sA + slot_a(r) * 1024);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            if constexpr (LW) blds16(rsW, min(woffp[(r * LW) & 1] + (unsigned)(slot_w(r) >> 1) * (unsigned)(32 * p.ldw), wmaxp[(r * LW) & 1]),
+            if constexpr (LW) blds16(rsW, min(woffp[(r * LW) & 1] + (unsigned)(slot_w(r) >> 1) * (unsigned)(16 * EB * p.ldw), wmaxp[(r * LW) & 1]),
                                      (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
             else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
         }
+        scale_piece(sA, kt);
         if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < ntaps_all) conv_tap_offsets(); } }
     };
 
@@ -482,10 +518,10 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool trans = (EK == 1 || EK == 2) ? false : (p.n_trans_begin >= 0) && (n0 >= p.n_trans_begin);
+    const bool trans = (EK == 1 || EK == 2 || EK == 4) ? false : (p.n_trans_begin >= 0) && (n0 >= p.n_trans_begin);
     // transposed tiles: square wave tiles swap the two LDS sources in the main loop (the lane then owns 4 consecutive m of one
     // n); every other tiling accumulates as usual and transposes while staging the stores through LDS
-    constexpr bool SQ = (FM == FN && TM == TN) && !PH;
+    constexpr bool SQ = (FM == FN && TM == TN) && !PH;            // (fp8 in either loop: no operand swap)
     const bool tswap = trans && SQ;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int fsw = (lane >> 1) & 7;                  // f(row) for fragment rows base + (lane & 31)
@@ -553,7 +589,7 @@ gemm_conv_kernel(const Params p) {
         }
     };
     // ---- software pipeline: NS-1 tiles requested ahead, NS-2 stay in flight across each barrier
-    if constexpr (PH) {
+    if constexpr (PHL) {
         constexpr int PL = PA + PB;                    // this wave's DMA instructions per slice
         static_assert(2 * PL <= 63, "vmcnt immediate");
         const int ns = p.K / (64 / EB);
@@ -707,9 +743,40 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
     for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));            // the prefetch touches have returned (older than the tiles waited for)
     int cur = 0, nxt = NS - 1;                        // ring positions of tile kt and tile kt+NS-1
-    constexpr int KPW = 4 / KS;                        // k-steps of this wave's split-K group
+    constexpr int KPW = F8L ? 2 : 4 / KS;              // k-steps of this wave's split-K group (fp8: two 64-wide k-steps per 128-byte row)
     const int k0 = kg * KPW;
-    frag_ab fa[2][FM], fb[2][FN];
+    typedef int v8i_t __attribute__((ext_vector_type(8)));
+    typedef std::conditional_t<F8L, v8i_t, frag_ab> frag_t;
+    frag_t fa[2][FM], fb[2][FN];
+    int f8a[2][(F8L && F8B) ? FM : 1];                 // MX-block scale of the A fragment (E8M0 byte in all four byte lanes), double-buffered with it
+    int f8sA[(F8L && !F8B) ? FM : 1], f8sW[F8L ? FN : 1];
+    if constexpr (F8L) {
+        const unsigned char* swp_ = p.scaleW + (int64_t)bz * p.strideScaleW;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) f8sW[j] = (int)(swp_[min(n0 + wc * TN + j * 32 + l31, p.N - 1)] * 0x01010101u);
+        if constexpr (!F8B) {
+            const unsigned char* sap_ = p.scaleA + (int64_t)bz * p.strideScaleA;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) f8sA[i] = (int)(sap_[min(m0 + wr * TM + i * 32 + l31, p.M - 1)] * 0x01010101u);
+        }
+    }
+    // one operand fragment of k-step kk from a row base inside the ring (operand layout of the scaled MFMA: tools/probe_mx.py, see the phase-offset loop)
+    auto rdfrag = [&](const char* row, int kk) __attribute__((always_inline)) -> frag_t {
+        if constexpr (F8L) {
+            const uint4 lo = *(const uint4*)(row + (((4 * kk + lhi) ^ fsw) << 4)), hi = *(const uint4*)(row + (((4 * kk + 2 + lhi) ^ fsw) << 4));
+            return (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        } else {
+            return *(const frag_ab*)(row + ((((k0 + kk) * 2 + lhi) ^ fsw) << 4));
+        }
+    };
+    auto rdscale = [&](int rbuf, int kk, int i) __attribute__((always_inline)) -> int {
+        return (int)((unsigned)(unsigned char)smem[rbuf * STAGE + A_TILE + B_TILE + (2 * kk + lhi) * BM + wr * TM + i * 32 + l31] * 0x01010101u);
+    };
+    auto mma = [&](f32x16& c, const frag_t& b_, const frag_t& a_, int j, int i, int S) __attribute__((always_inline)) {
+        if constexpr (ABL & 2) asm volatile("" :: "v"(b_), "v"(a_));
+        else if constexpr (F8L) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b_, a_, c, 0, 0, 0, f8sW[j], 0, F8B ? f8a[S][F8B ? i : 0] : f8sA[F8B ? 0 : i]);
+        else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_, a_, c, 0, 0, 0);
+    };
     constexpr int NMF = FM * FN, NRD = FM + FN;
     // One k-step with its issue order PINNED (a sched_barrier after every micro-group): MFMA q on register set S, then that
     // MFMA's share of the NEXT k-step's fragment reads (ring slot rbuf, k-step rkk, into set 1 - S: A fragments first, they feed
@@ -719,11 +786,10 @@ gemm_conv_kernel(const Params p) {
     // SINGLE-buffered -- fragment j is re-read for the next k-step right behind its last MFMA of this one, FM * (FN - 1 - j) + FM
     // MFMAs ahead of its next use -- and only the FM A fragments are double-buffered: 2 * FM + FN fragment registers instead of
     // 2 * (FM + FN), which is what keeps that tiling free of scratch spills (spill traffic would also break the counted vmcnt).
-    constexpr bool ROLL = NW * KS > 4 && NMF * 16 + 2 * NRD * 4 > 200;
+    constexpr bool ROLL = (NW * KS > 4 && NMF * 16 + 2 * NRD * 4 > 200) || (F8L && LW);
     auto kstep = [&](const int S, const int rbuf, const int rkk, const int nd, const int dbuf, const int dkt) {
         const char* pa = smem + rbuf * STAGE + off_a;
         const char* pb = smem + rbuf * STAGE + off_b;
-        const int sw = (((k0 + rkk) * 2 + lhi) ^ fsw) << 4;
         char* sA = smem + dbuf * STAGE;
         constexpr int RPQ = (NRD + NMF - 1) / NMF;
         const int dpq = (nd + NMF - 1) / NMF;
@@ -731,26 +797,24 @@ gemm_conv_kernel(const Params p) {
         for (int q = 0; q < NMF; ++q) {
             const int i = ROLL ? q % FM : q / FN, j = ROLL ? q / FM : q - (q / FN) * FN;
             const int SB = ROLL ? 0 : S;
-            if constexpr (ABL & 2) asm volatile("" :: "v"(fb[SB][j]), "v"(fa[S][i]));
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[SB][j], fa[S][i], acc[i][j], 0, 0, 0);
+            mma(acc[i][j], fb[SB][j], fa[S][i], j, i, S);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (ROLL) {
-                if (q < FM) fa[1 - S][q] = *(const frag_ab*)(pa + q * 32 * 128 + sw);
-                if (i == FM - 1) fb[0][j] = *(const frag_ab*)(pb + j * 32 * 128 + sw);
+                if (q < FM) { fa[1 - S][q] = rdfrag(pa + q * 32 * 128, rkk); if constexpr (F8L && F8B) f8a[1 - S][q] = rdscale(rbuf, rkk, q); }
+                if (i == FM - 1) fb[0][j] = rdfrag(pb + j * 32 * 128, rkk);
             } else {
 #pragma unroll
                 for (int u = 0; u < RPQ; ++u) {
                     const int r = q * RPQ + u;
-                    if (r < FM) fa[1 - S][r] = *(const frag_ab*)(pa + r * 32 * 128 + sw);
-                    else if (r < NRD) fb[1 - S][r - FM] = *(const frag_ab*)(pb + (r - FM) * 32 * 128 + sw);
+                    if (r < FM) { fa[1 - S][r] = rdfrag(pa + r * 32 * 128, rkk); if constexpr (F8L && F8B) f8a[1 - S][r] = rdscale(rbuf, rkk, r); }
+                    else if (r < NRD) fb[1 - S][r - FM] = rdfrag(pb + (r - FM) * 32 * 128, rkk);
                 }
             }
             if constexpr (!CONV && !LW) {
 #pragma unroll
                 for (int u = 0; u < dpq; ++u) {
                     const int r = q * dpq + u;
-                    if (r < RA && r < nd) blds16(rsA, aoff[r], (unsigned)dkt * (BK * 2), sA + slot_a(r) * 1024);
-                    else if (r < nd) blds16(rsW, woff[r - RA], (unsigned)dkt * (BK * 2), sA + A_TILE + slot_w(r - RA) * 1024);
+                    if (r < nd) dma_piece(r, sA, dkt);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -785,9 +849,8 @@ gemm_conv_kernel(const Params p) {
     static_assert(KPW == 1 || ((KPW - 1) & 1) == 1, "the next tile's first fragments go to register set 0");
 #pragma unroll
     for (int r = 0; r < NRD; ++r) {
-        const int sw0 = ((k0 * 2 + lhi) ^ fsw) << 4;
-        if (r < FM) fa[0][r] = *(const frag_ab*)(smem + off_a + r * 32 * 128 + sw0);
-        else fb[0][r - FM] = *(const frag_ab*)(smem + off_b + (r - FM) * 32 * 128 + sw0);
+        if (r < FM) { fa[0][r] = rdfrag(smem + off_a + r * 32 * 128, 0); if constexpr (F8L && F8B) f8a[0][r] = rdscale(0, 0, r); }
+        else fb[0][r - FM] = rdfrag(smem + off_b + (r - FM) * 32 * 128, 0);
     }
     int kt = 0;
     for (; kt + NS - 1 < nk; ++kt) ktile(kt, std::true_type{});
@@ -1337,7 +1400,8 @@ gemm_conv_kernel(const Params p) {
         if constexpr (F8C) f8q = p.f8copy != nullptr;
         // flavour bits: 1 straight-line, 2 row statistics, 4 e4m3 copy, 8 column statistics
         // (8: column statistics for a GroupNorm behind this launch -- never together with row statistics or the e4m3 copy, gemm_conv.hip)
-        if constexpr (CS) { if (!fastp) chunks(std::integral_constant<int, 8>{}); else chunks(std::integral_constant<int, 9>{}); }
+        if constexpr (EK == 4) { if constexpr (F8C) { if (!sto) chunks(std::integral_constant<int, 5>{}); else chunks(std::integral_constant<int, 7>{}); } }     // (the host sends only such launches here)
+        else if constexpr (CS) { if (!fastp) chunks(std::integral_constant<int, 8>{}); else chunks(std::integral_constant<int, 9>{}); }
         else if (!fastp) chunks(std::integral_constant<int, 0>{});
         else if (!f8q) { if (!sto) chunks(std::integral_constant<int, 1>{}); else chunks(std::integral_constant<int, 3>{}); }
         else { if constexpr (F8C) { if (!sto) chunks(std::integral_constant<int, 5>{}); else chunks(std::integral_constant<int, 7>{}); } }
@@ -1475,7 +1539,7 @@ constexpr int NUM_CFG = 21;
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
     static_assert(KS == 1 || BM * BN * 4 <= NS * (BM + BN) * 128, "the split-K hand-over must fit in the staging ring");
-    constexpr int SMEM = (PH ? 4 * (BM + BN) * 64 : NS * (BM + BN) * 128) + (BM + BN) * 16 + BM * 4 + BN * 4 + (CONV ? BN * 4 : 0)      // staging ring + fused-LayerNorm block + the tile's bias (+ time-embedding row)
+    constexpr int SMEM = ((PH >= 1 && PH <= 3) ? 4 * (BM + BN) * 64 : NS * ((BM + BN) * 128 + (PH == 5 ? 1024 : 0))) + (BM + BN) * 16 + BM * 4 + BN * 4 + (CONV ? BN * 4 : 0)      // staging ring + fused-LayerNorm block + the tile's bias (+ time-embedding row)
                        + (PH == 3 ? BM * f8_block_cap(BN) : 0);                                          // + the tile's MX block scales of A
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;   // idempotent; racing threads set the same value
@@ -1508,6 +1572,7 @@ int launch_cs(Params& p, int batch, hipStream_t st) {
         if (p.S1) return p.cs_out ? launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2, 1>(p, batch, st) : launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2, 1>(p, batch, st);
     }
     if constexpr (CSOK) { if (p.cs_out) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2>(p, batch, st); }         // (validated: plain staged epilogue)
+    if constexpr (LW && PH >= 4) { if (p.f8copy) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 4>(p, batch, st); }   // (gemm_conv.hip:launch sends only straight-line launches here)
     if constexpr (!CONV) { if (no_trans && p.epilogue == TMIX_EPI_GEGLU && (p.wide & 2)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 1>(p, batch, st); }
     if (no_trans && p.epilogue != TMIX_EPI_GEGLU && (p.wide & 1)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2>(p, batch, st);
     if constexpr (!CONV) { if (!no_trans && p.epilogue != TMIX_EPI_GEGLU && (p.wide & 1) && (p.wide & 4)) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 3>(p, batch, st); }
@@ -1520,5 +1585,6 @@ int launch_group1(int cfg, int conv, int f8, Params& p, int batch, hipStream_t s
 int launch_group2(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
 int launch_group3(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
 int launch_group4(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
+int launch_group5(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);      // fp8 in the lock-step loops (f8 = 3: per-row A scales, 4: MX blocks)
 
 }  // namespace tmix_gemm

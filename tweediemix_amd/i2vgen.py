@@ -226,6 +226,8 @@ class I2VPlan(UNetPlan):
         self.row_sets, self.routed, self._rows_cache = list(range(B)), False, {}
         self.lowrank, self._sets_dev = False, None       # (no LoRA routing in the video UNet; UNetPlan's emitters ask -- tests/test_plan_attrs_cpu.py keeps this list honest)
         self.fp8_chain_ff = False
+        self.fp8_attn_out = False
+        self.fp8_tile = 0
         self._gn_fused = False                           # GroupNorm statistics stay with the statistics kernel here: the temporal norms span 16 frames
                                                          # (86,016 rows per clip, beyond ops.COLSTATS_MAX_HW) and the injection sites rewrite resnet outputs in place
         self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")      # conv_shortcut in conv2's launch, no concat launches (UNetPlan._resnet)

@@ -392,6 +392,8 @@ class UNetPlan:
         # their A operand is quantised by one tmix_quantize_fp8_rows launch in front of the GEMM
         self.fp8 = bool(fp8)
         self.fp8_chain_ff = not os.environ.get("TMIX_FP8_FF_ROWS")    # =1: quantise the FF intermediate per row with a separate launch
+        self.fp8_attn_out = not os.environ.get("TMIX_FP8_NO_ATTN_OUT")  # =1: attention output in bf16, out-projections on bf16 operands (round 3)
+        self.fp8_tile = int(os.environ.get("TMIX_FP8_TILE", "21"))      # 128 x 160 e4m3 tiling of the N = 1280 / 640 launches (21: loader waves, 12: none, 0: phase-offset only)
         self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
         # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
@@ -613,8 +615,13 @@ class UNetPlan:
             assert a2.data_ptr() == a.data_ptr() and a2.stride(1) == 1          # a view, rows contiguous in K
             self._emit(self.lib.tmix_quantize_fp8_rows, a2.data_ptr(), a2.stride(0), a8.data_ptr(), K, sa.data_ptr(), a2.shape[0], K)
             owned = (a8, sa)
+        # the N = 1280 / 640 launches (attention out-projections, attn2 to_q, FF2): 128 x 160 tiles fill the chip where 256 x 128 leaves 96 CUs idle, and
+        # on e4m3 operands the lock-step loop with loader waves runs FF2 at 1.7 PFLOP/s (31 us against 45.5 for the phase-offset 256 x 128, 51.5 in bf16)
+        Ng, Kg = w8.shape[-2], w8.shape[-1]
+        if self.fp8_tile and f8_out is None and kw.get("out_t") is None and Kg % 128 == 0 and Ng % 160 == 0 and Ng <= 1280:
+            kw.setdefault("tile_cfg", self.fp8_tile)
         if kw.get("row_stats_out") is not None:
-            kw.setdefault("tile_cfg", 17)           # explicit (the partial count depends on it); fp8 runs the phase-offset tilings only
+            kw.setdefault("tile_cfg", 17)           # explicit (the partial count depends on it)
         d = ops.make_gemm_desc(a8, w8, None if f8_out is not None else out, **kw)
         if f8_out is not None:
             c8, cs = f8_out
@@ -680,11 +687,20 @@ class UNetPlan:
             for c in cons:
                 c.ln_parts = parts
 
-    def _attn(self, q, k, vt, out, H, Sq, Skv):
-        args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
-                vt.data_ptr(), vt.stride(1), vt.stride(0), out.data_ptr(), out.stride(1), out.stride(0),
-                self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5)
-        self._emit(self.lib.tmix_attn_fwd, *args)
+    def _attn(self, q, k, vt, out, H, Sq, Skv, f8_out=None):
+        """f8_out: an ops.F8Copy that receives the output as e4m3 + MX block scales instead of the bf16 tensor `out` (fp8 plans: the out-projection's
+        A operand without a quantiser launch and with half the bytes)"""
+        if f8_out is not None:
+            args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
+                    vt.data_ptr(), vt.stride(1), vt.stride(0), f8_out.q.data_ptr(), f8_out.N, f8_out.scales.data_ptr(), f8_out.rows,
+                    self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5)
+            self._emit(self.lib.tmix_attn_fwd_f8, *args)
+            self.keep.append(f8_out)
+        else:
+            args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
+                    vt.data_ptr(), vt.stride(1), vt.stride(0), out.data_ptr(), out.stride(1), out.stride(0),
+                    self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5)
+            self._emit(self.lib.tmix_attn_fwd, *args)
         fl = 4 * self.B * H * Sq * Skv * 64
         self.flops += fl
         self.launches["attn"].append((args, fl))
@@ -797,6 +813,10 @@ class UNetPlan:
         if self.fp8 and self.fp8_chain_ff and n and S % 32 == 0 and Cc % 32 == 0:
             h8buf = A.get(ops.F8Copy.bytes_for(B * S, Cc), dtype=torch.uint8)
             h8 = ops.F8Copy(B * S, Cc, self.dev, buf=h8buf)
+        ao8 = ao8buf = None
+        if h8 is not None and self.fp8_attn_out:
+            ao8buf = A.get(ops.F8Copy.bytes_for(B * S, Cc), dtype=torch.uint8)
+            ao8 = ops.F8Copy(B * S, Cc, self.dev, buf=ao8buf)
         self._gemm(g.view(B * S, Cc), W[name + ".proj_in.weight"], h.view(B * S, Cc), bias=W[name + ".proj_in.bias"],
                    row_stats_out=st if n else None, f8_copy=h8)
         A.put(g)
@@ -807,21 +827,31 @@ class UNetPlan:
             # --- self attention; norm1 is folded into the q/k/v projection
             qk = A.get(B, S, 2 * Cc)
             self._proj(h, a1 + ".qkv", qk, S, Cc, ln=st, out_t=vt, n_trans_begin=2 * Cc, fp8=True, a8=h8, a_full=h_full)
-            ao_full = A.get(B, S, Cc + pad)
-            ao = ao_full[:, :, :Cc] if pad else ao_full
-            self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
-            A.put(qk)
-            self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
-            A.put(ao_full)
+            if ao8 is not None:                        # fp8 plans: attention output as e4m3 + MX blocks, out-projection on e4m3 operands
+                self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, None, H, S, S, f8_out=ao8)
+                A.put(qk)
+                self._proj(ao8.q.view(B, S, Cc), a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, fp8=True, a8=ao8)
+            else:
+                ao_full = A.get(B, S, Cc + pad)
+                ao = ao_full[:, :, :Cc] if pad else ao_full
+                self._attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, ao, H, S, S)
+                A.put(qk)
+                self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
+                A.put(ao_full)
             # --- cross attention against the cached K / V^T; norm2 folded into to_q
             q = A.get(B, S, Cc)
             self._proj(h, a2 + ".q", q, S, Cc, ln=st, fp8=h8 is not None, a8=h8, a_full=h_full)
-            ao_full = A.get(B, S, Cc + pad)
-            ao = ao_full[:, :, :Cc] if pad else ao_full
-            self._attn(q, self.kv.k[a2], self.kv.vt[a2], ao, H, S, self.kv.Lk)
-            A.put(q)
-            self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
-            A.put(ao_full)
+            if ao8 is not None:
+                self._attn(q, self.kv.k[a2], self.kv.vt[a2], None, H, S, self.kv.Lk, f8_out=ao8)
+                A.put(q)
+                self._proj(ao8.q.view(B, S, Cc), a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, fp8=True, a8=ao8)
+            else:
+                ao_full = A.get(B, S, Cc + pad)
+                ao = ao_full[:, :, :Cc] if pad else ao_full
+                self._attn(q, self.kv.k[a2], self.kv.vt[a2], ao, H, S, self.kv.Lk)
+                A.put(q)
+                self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
+                A.put(ao_full)
             # --- feed forward: norm3 folded into the first GEMM, GEGLU fused in its epilogue
             if self.fp8 and self.fp8_chain_ff:
                 # the intermediate leaves FF1 as e4m3 with one E8M0 scale per 32 columns and FF2 reads it as block-scaled A
@@ -846,6 +876,8 @@ class UNetPlan:
         A.put(h_full)
         if h8 is not None:
             A.put(h8buf)
+        if ao8buf is not None:
+            A.put(ao8buf)
         return out
 
     def _cat(self, x1, C1, x2, C2, HW):
@@ -978,7 +1010,7 @@ class UNetPlan:
             if rc:
                 L.check(rc, fn.__name__)
             m = self.op_meta.get(i)
-            if not m or m[0] != "gemm" or id(m[2]) not in prods:
+            if not m or m[0] not in ("gemm", "gemm_fp8") or id(m[2]) not in prods:
                 continue
             d = m[2]
             torch.cuda.synchronize()
