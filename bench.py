@@ -249,7 +249,8 @@ def insitu_profile(tw, reps=3):
             end = b
         return tot * tick
 
-    out = {"replay_ms": wall_ms, "uninstrumented_replay_ms": plain_ms}
+    out = {"replay_ms": wall_ms, "uninstrumented_replay_ms": plain_ms, "launches_total": len(meta),
+           "boundaries_ms": sum((int(sl[i + 1][0]) - int(sl[i][1])) for i in range(len(meta) - 1)) * tick}      # start(i+1) - end(i), summed
     all_iv = []
     for cls, c in by.items():
         all_iv += c["iv"]
@@ -269,7 +270,7 @@ def fp8_roofline(prof):
     g8, g16 = prof.get("gemm_fp8"), prof.get("gemm")
     if not g8:
         return None
-    out = {"bound": "mfma", "kernel": "gemm_conv_kernel<..,PH=2|3> (tmix_gemm_fp8, v_mfma_scale_f32_32x32x64_f8f6f4)",
+    out = {"bound": "mfma", "kernel": "gemm_conv_kernel<..,PH=2..5> (tmix_gemm_fp8, v_mfma_scale_f32_32x32x64_f8f6f4)",
            "achieved": g8["tflops"], "peak": FP8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g8["tflops"] / FP8_DENSE_PEAK_TFLOPS,
            "launches_per_step": g8["launches"], "avg_launch_us": g8["avg_launch_us"], "flops_per_step": g8["flops"],
            "sum_launch_ms": g8["sum_launch_ms"], "graph_replay_ms": prof["replay_ms"],
@@ -291,6 +292,22 @@ def gemm_alg_bytes(plan):
     return gb / max(1, len(plan.launches["gemm"]))
 
 
+def conv_alg_bytes(plan):
+    """algorithmic HBM bytes of the convolution launches: input (+ shortcut inputs) read once, weights once, output written once, residual once."""
+    try:
+        tot, n = 0, 0
+        for p in ([plan] if hasattr(plan, "launches") else plan.plans):
+            for d, _f in p.launches["conv"]:
+                half = d.mode in (1, 4)
+                ho, wo = (d.H // 2, d.W // 2) if half else ((d.H * 2, d.W * 2) if d.mode == 2 else (d.H, d.W))
+                csc = d.S1_channels + d.S2_channels
+                tot += 2 * (d.B * d.H * d.W * d.Cin + d.B * ho * wo * csc + d.Cout * (9 * d.Cin + csc) + d.B * ho * wo * d.Cout * (2 if d.residual else 1))
+                n += 1
+        return tot / max(1, n)
+    except Exception:
+        return None
+
+
 def pmc_evidence():
     """the committed rocprofv3 PMC passes this line cites, named by profiles/MANIFEST.json (not "whatever file sorts last"):
     HBM bytes per GEMM launch (FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md section HBM) and the
@@ -302,7 +319,8 @@ def pmc_evidence():
         tr = json.load(open(os.path.join(ROOT, "profiles", man["traffic"])))
         traffic = float(tr["gemm"]["hbm_bytes_per_launch_corrected"])
         mu = json.load(open(os.path.join(ROOT, "profiles", man["mfma_util"])))["per_kernel_class_time_weighted_percent"]
-        return traffic, {"files": man, "mfma_util_percent": mu}
+        return traffic, {"files": man, "mfma_util_percent": mu,
+                         "traffic_bytes_per_launch_by_class": {k: float(v["hbm_bytes_per_launch_corrected"]) for k, v in tr.items()}}
     except Exception as e:                    # no profile committed (or an unreadable one): say so instead of guessing
         return None, {"files": None, "error": repr(e)}
 
@@ -411,7 +429,7 @@ def video_step_bench(steps=8, warmup=2, res_w=768, res_h=448, frames=16, streams
     from tweediemix_amd.weights import synthetic_i2vgen_state_dict
     h, w, Fr = res_h // 8, res_w // 8, frames
     t0 = time.perf_counter()
-    sd = {k: v.to(torch.bfloat16) for k, v in synthetic_i2vgen_state_dict(I.FULL).items()}
+    sd = synthetic_i2vgen_state_dict(I.FULL, dtype=torch.bfloat16, device="cuda")        # drawn on the device: plan_build_s 24 -> ~2 s
     Wt = I.I2VWeights(I.FULL, sd)
     del sd
     g = torch.Generator().manual_seed(0)
@@ -602,9 +620,10 @@ def main(argv=None):
         if args.dtype == "bf16" and not args.tiny:
             tw3, _parts3 = build_sampler(args, primary, device, seed=rank, fp8=True)
             dt3, _ = timed_fusion_steps(tw3, args, world, device, x)
-            other["fp8"] = {"workload": f"{primary} deltas; attn1 q/k/v and the two FF projections of every transformer block on e4m3 operands with "
-                                        "power-of-two scales (tmix_gemm_fp8): per row behind a quantiser launch (q/k/v, FF1), FF1 -> FF2 chained through MX blocks "
-                                        "of 32 emitted by the GEGLU epilogue; everything else bf16",
+            other["fp8"] = {"workload": f"{primary} deltas; every projection of every transformer block (attn1 q/k/v, both attention out-projections, attn2 to_q, FF1, "
+                                        "FF2: 420 of the 442 GEMM launches) on e4m3 operands with power-of-two scales (tmix_gemm_fp8); no quantiser launch inside a block: "
+                                        "the GEMMs that write the residual stream and the attention kernels (tmix_attn_fwd_f8) leave e4m3 + MX-block copies, FF1 -> FF2 "
+                                        "chained through the GEGLU epilogue; proj_in / proj_out, convolutions and the attention inner products stay bf16",
                             "dtype": "fp8", "value": S_ * args.steps / dt3, "unit": "steps/s", "ms_per_step": 1e3 * dt3 / (args.steps * S_),
                             "parity_check": parity_check(tw3, args, _parts3, primary, device)}
             if rank == 0:
@@ -646,6 +665,9 @@ def main(argv=None):
                          "how": "achieved = sum(2MNK of the step's GEMM launches) / sum(their durations), each launch timed on the device clock "
                                 "INSIDE the captured step while the graph replays (concurrent chains included, so the sum can exceed the wall time)",
                          "launches_per_step": g["launches"], "avg_launch_us": g["avg_launch_us"], "flops_per_step": g["flops"],
+                         "launches_per_step_all_classes": prof["launches_total"], "kernel_boundaries_ms": prof["boundaries_ms"],
+                         "conv": {"traffic": (pmc[1].get("traffic_bytes_per_launch_by_class") or {}).get("conv"),
+                                  "algorithmic_bytes_per_launch": conv_alg_bytes(plan), "achieved": (prof.get("conv") or {}).get("tflops")},
                          "graph_replay_ms": prof["replay_ms"], "uninstrumented_graph_replay_ms": prof["uninstrumented_replay_ms"],
                          "instrumented_busy_ms": prof["instrumented_busy_ms"],
                          "classes": {k: {kk: v[kk] for kk in ("launches", "sum_launch_ms", "busy_ms", "avg_launch_us", "tflops")}

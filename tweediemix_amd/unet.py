@@ -462,7 +462,8 @@ class UNetPlan:
         if kind == "gemm":
             return repr((kind, d.M, d.N, d.K, d.batch, d.epilogue, d.n_trans_begin >= 0, bool(d.residual), d.strideW != 0,
                          bool(d.row_stats_out), bool(d.ln_stats)))
-        return repr((kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode))
+        csc = d.S1_channels + d.S2_channels          # shortcut taps ride in the K loop (K = 9 Cin + csc): a shape of its own
+        return repr((kind, d.B, d.H, d.W, d.Cin, d.Cout, d.mode) + ((csc,) if csc else ()))
 
     def autotune(self, reps=None):
         """pick the fastest workgroup tiling (TMIX_TILE_*) per distinct GEMM / conv shape (the shapes of this path are
@@ -1063,7 +1064,7 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
     for p in plans:
         for _i, kind, d in p._tunable:
             k = p._tune_key(kind, d)
-            fl = 2.0 * d.M * d.N * d.K * d.batch if kind == "gemm" else 2.0 * d.B * d.H * d.W * d.Cout * 9 * d.Cin
+            fl = 2.0 * d.M * d.N * d.K * d.batch if kind == "gemm" else 2.0 * d.B * d.H * d.W * d.Cout * (9 * d.Cin + d.S1_channels + d.S2_channels)
             weight[k] = weight.get(k, 0.0) + fl
             members.setdefault(k, []).append((p, kind, d))
     base = timed()
