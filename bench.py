@@ -401,14 +401,27 @@ def run_trajectories(tw, args, rank, world, device):
     local = torch.cat(lats) if lats else torch.zeros(0, 4, tw.h, tw.w, device=device)
     torch.cuda.synchronize()
     assert torch.isfinite(local).all()
+    t_local = time.perf_counter() - t1                 # this rank's own seeds, before the gather
+    gather_s = 0.0
     if args.num_seeds:                                 # the result gather: the only collective of the path (a one-rank group at N = 1)
+        tg = time.perf_counter()
         gathered = D.gather_latents(local.contiguous(), total, rank, world)
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - tg            # (includes waiting for the slowest rank)
         assert gathered.shape[0] == total and torch.isfinite(gathered).all()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     import torch.distributed as dist
+    per_rank = [len(mine) / t_local if t_local > 0 else 0.0]
     if dist.is_initialized():
-        dt = D.max_over_ranks(dt, torch.device("cpu") if dist.get_backend() == "gloo" else device)
+        cdev = torch.device("cpu") if dist.get_backend() == "gloo" else device
+        dt = D.max_over_ranks(dt, cdev)
+        pr = torch.zeros(world, dtype=torch.float64, device=cdev)
+        pr[rank] = per_rank[0]
+        dist.all_reduce(pr)
+        per_rank = [float(v) for v in pr.cpu()]
+    out["per_rank_images_per_s"] = per_rank
+    out["gather_s"] = gather_s
     del co
     torch.cuda.empty_cache()
     out.update({"images": total, "seconds": dt, "images_per_s": total / dt if dt > 0 else 0.0, "cobatch": C_,
