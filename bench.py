@@ -621,6 +621,7 @@ def main(argv=None):
     other = {}
     if args.kind == "both" and world == 1:
         alg = gemm_alg_bytes(plan)
+        conv_alg = conv_alg_bytes(plan)
         flops_step = plan.flops
         del tw, plan
         torch.cuda.empty_cache()
@@ -647,6 +648,7 @@ def main(argv=None):
             other["video"] = video_step_bench()
     else:
         alg = gemm_alg_bytes(plan)
+        conv_alg = conv_alg_bytes(plan)
         flops_step = plan.flops
 
     if rank == 0:
@@ -680,7 +682,7 @@ def main(argv=None):
                          "launches_per_step": g["launches"], "avg_launch_us": g["avg_launch_us"], "flops_per_step": g["flops"],
                          "launches_per_step_all_classes": prof["launches_total"], "kernel_boundaries_ms": prof["boundaries_ms"],
                          "conv": {"traffic": (pmc[1].get("traffic_bytes_per_launch_by_class") or {}).get("conv"),
-                                  "algorithmic_bytes_per_launch": conv_alg_bytes(plan), "achieved": (prof.get("conv") or {}).get("tflops")},
+                                  "algorithmic_bytes_per_launch": conv_alg, "achieved": (prof.get("conv") or {}).get("tflops")},
                          "graph_replay_ms": prof["replay_ms"], "uninstrumented_graph_replay_ms": prof["uninstrumented_replay_ms"],
                          "instrumented_busy_ms": prof["instrumented_busy_ms"],
                          "classes": {k: {kk: v[kk] for kk in ("launches", "sum_launch_ms", "busy_ms", "avg_launch_us", "tflops")}
