@@ -119,7 +119,8 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_128x160_S3_LW = 19 /* 128x160, 3-deep ring, plus ONE loader wave: the four math waves issue no VMEM instruction in the K loop */,
        TMIX_TILE_128x160_S4_LW2 = 20 /* tiling 12 plus TWO loader waves (each issues every other LDS-DMA instruction of a K-tile) */,
        TMIX_TILE_128x160_S4_LW4 = 21 /* tiling 12 plus FOUR loader waves: one per SIMD, nine LDS-DMA instructions of a K-tile each */,
-       TMIX_TILE_COUNT = 21 };
+       TMIX_TILE_256x320_PH = 22 /* 256x320 with the phase-offset mainloop (eight waves of 64x160): bf16 GEMM, no transposed region */,
+       TMIX_TILE_COUNT = 22 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */
@@ -222,6 +223,11 @@ typedef struct {
     int32_t S1_channels, S2_channels;
 } tmix_conv_desc;
 int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream);
+/* the same convolution (diffusers ResnetBlock2D.conv1 / conv2 behind fusion_sampling.py:340) on OCP e4m3 operands: X = e4m3 bytes [B,H,W,Cin] with one E8M0
+ * scale per (pixel, 32 channels) in the ROW-major form scale_x [B*H*W][Cin/32] -- what tmix_groupnorm_nhwc_pre_f8 writes -- Wt = e4m3 bytes [Cout][taps*Cin] with one
+ * E8M0 scale per output channel (tmix_quantize_fp8_rows over the weight rows).  Cin %% 128 == 0 (a K-tile is 128 channels of one tap), no shortcut taps;
+ * Y, bias, batch_bias, residual, col_stats_out as in tmix_conv3x3_nhwc.  tile_cfg: 12 or 20 (128x160 without / with two loader waves). */
+int tmix_conv3x3_nhwc_fp8(const tmix_conv_desc* d, const uint8_t* scale_x, const uint8_t* scale_w, void* stream);
 
 /* conv_in: fp32 NCHW latent [B,4,H,W] -> bf16 NHWC [B,H,W,Cout] (Cout % 32 == 0); weights fp32 OHWI. */
 int tmix_conv_in(const float* x_nchw, const float* w_ohwi, const float* bias, void* y_nhwc,
@@ -273,6 +279,11 @@ int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y,
 int tmix_groupnorm_nhwc_pre(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                             const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
                             const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream);
+/* tmix_groupnorm_nhwc_pre with the normalised (+ SiLU) tensor written as e4m3 bytes Y8 [B*HW][C] + scales [B*HW][C/32] (row-major MX blocks; C %% 32 == 0):
+ * the input of tmix_conv3x3_nhwc_fp8; bit for bit what an MX quantiser makes of the bf16 tensor tmix_groupnorm_nhwc_pre writes. */
+int tmix_groupnorm_nhwc_pre_f8(const void* X1, int C1, const void* X2, int C2, void* Y8, void* scales, const float* gamma,
+                               const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                               const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream);
 int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta, int64_t rows, int C,
                    float eps, void* stream);
 /* hipMemsetAsync(ptr, 0, nbytes) on the stream (graph-capturable): zeroes the LayerNorm statistics accumulators */

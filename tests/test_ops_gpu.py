@@ -188,7 +188,7 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
                                    (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
 def test_gemm_plain(ops, M, N, K, cfg):
@@ -197,7 +197,7 @@ def test_gemm_plain(ops, M, N, K, cfg):
     close(out, a.float() @ w.float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
@@ -209,7 +209,7 @@ def test_gemm_epilogues(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
@@ -236,7 +236,7 @@ def test_gelu_epilogue_is_the_exact_erf_form_also_in_the_tail(ops):
     assert rel.max().item() < 2 ** -8 * 1.01 + 1e-5, rel.max().item()        # bf16 rounding of the result + 1e-5 of the function itself
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     Bz, M, C = 3, 100, 128
     a = rnd(Bz, M, C, seed=11)
@@ -254,7 +254,7 @@ def test_gemm_batched_weights_and_transposed_out(ops, cfg):
     close(out, big[:, :, C:].float() @ w[0].float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17, 18, 21])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17, 18, 21, 22])
 def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch):
     """the LDS-staged 16-byte stores (default) against the accumulator-layout 8-byte stores (TMIX_NARROW_EPILOGUE=1, the
     fallback for unaligned rows): same values, same operation order per element => identical C, GEGLU output and V^T; the
@@ -456,7 +456,7 @@ def _colstats_close(cs, out):
     assert (err <= tol).all(), f"max err {err.max().item():.4g} at {ref.abs().max().item():.4g}"
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 @pytest.mark.parametrize("M,N,K,res", [(256, 320, 128, True), (1024, 1280, 64, True), (96, 200, 64, False), (4096, 640, 64, False)])
 def test_gemm_leaves_groupnorm_column_statistics(ops, cfg, M, N, K, res):
     """col_stats_out: the producer-side GroupNorm statistics (straight-line and generic staged epilogues, every tiling, ragged tile edges)"""
@@ -546,6 +546,60 @@ def test_groupnorm_from_producer_partials(ops, B, HW, C1, C2, silu):
         assert torch.equal(yc, y)
 
 
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 640, 0, True), (1, 1024, 1280, 640, True), (2, 64, 640, 320, False), (1, 4096, 640, 0, True)])
+def test_groupnorm_output_as_e4m3_with_row_major_mx_scales(ops, B, HW, C1, C2, silu):
+    """tmix_groupnorm_nhwc_pre_f8: bytes and scales equal a torch MX quantiser applied to the bf16 tensor the plain kernel writes; the scales in the
+    ROW-major form [pixels][C / 32] tmix_conv3x3_nhwc_fp8 gathers."""
+    x1 = rnd(B, HW, C1, seed=70) + 0.5
+    x1[:, :, 7] *= 60.0                                         # a loud channel: its block gets its own scale
+    x2 = rnd(B, HW, C2, seed=71) * 2 if C2 else None
+    Cc = C1 + C2
+    g, b = rnd(Cc, seed=72, dtype=torch.float32), rnd(Cc, seed=73, dtype=torch.float32)
+    cs = (_colstats_ref(x1).float().contiguous(), _colstats_ref(x2).float().contiguous() if C2 else None)
+    y = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2, colstats=cs)
+    y8 = torch.full((B, HW, Cc), 0x5a, device="cuda", dtype=torch.uint8)
+    s8 = torch.full((B * HW, Cc // 32), 0x5a, device="cuda", dtype=torch.uint8)
+    ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2, colstats=cs, f8_out=(y8, s8))
+    torch.cuda.synchronize()
+    q, sc, _deq = _mx_quantize(y.float().view(B * HW, Cc))       # scales come back k-block major [C/32][rows]
+    assert torch.equal(s8, sc.t().contiguous())
+    same = (y8.view(B * HW, Cc) == q) | (((y8.view(B * HW, Cc) & 0x7f) == 0) & ((q & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+
+
+@pytest.mark.parametrize("cfg", [12, 20])
+@pytest.mark.parametrize("mode,B,H,W,Cin,Cout,extra", [(0, 2, 16, 16, 256, 320, "tr"), (0, 1, 32, 32, 1280, 1280, "r"), (1, 2, 16, 16, 128, 160, ""), (2, 1, 8, 12, 256, 256, "t"),
+                                                        (0, 4, 8, 8, 640, 640, "c")])
+def test_conv3x3_fp8_equals_the_conv_of_the_dequantised_operands(ops, cfg, mode, B, H, W, Cin, Cout, extra):
+    """tmix_conv3x3_nhwc_fp8 (e4m3 input with row-major MX block scales, e4m3 weights with one scale per output channel; a K-tile = 128 channels of one
+    tap, the scales gathered per tap with a 4-byte LDS-DMA per row) against F.conv2d of exactly the values it reads; padding, stride 2, nearest x2,
+    time-embedding bias, residual and the GroupNorm column statistics as in the bf16 kernel."""
+    x = rnd(B, H, W, Cin, seed=300, dtype=torch.float32)
+    x[..., 40:72] *= 23.0
+    w = rnd(Cout, 3, 3, Cin, seed=301, scale=(9 * Cin) ** -0.5)
+    q, sc, xd = _mx_quantize(x.view(B * H * W, Cin))
+    sx = sc.t().contiguous()
+    w8, sw = ops.quantize_fp8_rows(w.view(Cout, 9 * Cin))
+    wd = ops.dequantize_fp8_rows(w8, sw).view(Cout, 3, 3, Cin)
+    bias = rnd(Cout, seed=302, dtype=torch.float32)
+    Ho, Wo = ops.conv_out_hw(H, W, mode)
+    temb = rnd(B, Cout, seed=303, dtype=torch.float32) if "t" in extra else None
+    res = rnd(B, Ho, Wo, Cout, seed=304) if "r" in extra else None
+    cs = torch.full((B * Ho * Wo // 32, 2, Cout), float("nan"), device="cuda") if "c" in extra else None
+    out = ops.conv3x3_fp8(q.view(B, H, W, Cin), sx, w8.view(Cout, 3, 3, Cin), sw, bias=bias, batch_bias=temb, residual=res, mode=mode, tile_cfg=cfg, col_stats_out=cs)
+    xin = xd.view(B, H, W, Cin).permute(0, 3, 1, 2)
+    if mode == 2:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wd.permute(0, 3, 1, 2), bias, stride=2 if mode == 1 else 1, padding=1).permute(0, 2, 3, 1)
+    if temb is not None:
+        ref = ref + temb[:, None, None, :]
+    if res is not None:
+        ref = ref + res.float()
+    close(out, ref, rtol=2 ** -6, atol_frac=4e-3)
+    if cs is not None:
+        _colstats_close(cs, out)
+
+
 def test_conv_groupnorm_chain_through_the_partials(ops):
     """conv -> GroupNorm + SiLU as the UNet plan issues it: conv with col_stats_out, then tmix_groupnorm_nhwc_pre"""
     B, H, W, Cin, Cout = 2, 32, 32, 64, 320
@@ -608,7 +662,7 @@ def test_concat_and_embedding_and_linear_small(ops):
         torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15, 20, 21])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15, 20, 21, 22])
 def test_gemm_fused_layernorm_pair(ops, cfg):
     """producer GEMM emits row statistics of what it stored, consumer GEMM applies LayerNorm algebraically:
     together == Linear2(LayerNorm(Linear1(a) + res)) of diffusers' BasicTransformerBlock."""

@@ -28,7 +28,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         }
     }
     if (p.f8copy) {                // the e4m3 copy of C is compiled into the tilings that have registers to spare for it (F8C)
-        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12};
+        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12, 12};
         // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
         if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
         if (!(cfg == 21 && !conv && p.scaleA && p.K % 128 == 0)) cfg = alt[cfg];      // (tiling 21 on e4m3 operands carries the copy itself)
@@ -55,6 +55,10 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         if (p.stats_out && asked != cfg) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg %d cannot run this launch (K / 32 = %d block scales per row exceed the 256x256 tile's LDS budget); "
                                                                 "with row_stats_out request tile_cfg 17 explicitly", asked, p.K / 32);
     }
+    if (conv && p.scaleA) {     // convolution on e4m3 operands: the 128 x 160 lock-step tilings, with two loader waves (20) or without (12)
+        f8 = 4;
+        cfg = (cfg == 20 || cfg == 21 || cfg == 19) ? 20 : 12;
+    } else
     if (conv) {
         // the phase-offset and loader-wave mainloops exist for the plain GEMM only (the im2col gather's per-row offset tables do
         // not fit a loader wave's register budget, and the conv mainloop already runs at 0.8-1.0 PFLOP/s): nearest plain tiling
@@ -62,10 +66,13 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         // 244 VGPRs, no scratch; not with shortcut taps, whose source switch lives in the staging path of the math waves' kernel)
         if (cfg == 16) cfg = 4;
         else if (cfg == 17) cfg = 2;
+        else if (cfg == 22) cfg = 14;
         else if (cfg >= 18 && (cfg != 20 || p.S1)) cfg = 12;
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
+    // 256x320 phase-offset: bf16, staged GEGLU / plain epilogues only (the transposed and narrow forms spill at its register count)
+    if (!conv && cfg == 22 && (f8 || p.n_trans_begin >= 0 || !(p.epilogue == TMIX_EPI_GEGLU ? (p.wide & 2) : (p.wide & 1)))) cfg = f8 ? 16 : 14;
     // column statistics (cs_out) are compiled for the lock-step tilings only: the phase-offset ones run as their nearest plain tiling
-    if (p.cs_out) { if (cfg == 16) cfg = 4; else if (cfg == 17) cfg = 2; }
+    if (p.cs_out) { if (cfg == 16) cfg = 4; else if (cfg == 17) cfg = 2; else if (cfg == 22) cfg = 14; }
     int rc = f8 >= 3 ? -999 : launch_group0(cfg, conv, f8, p, batch, st);
     if (rc == -999 && f8 < 3) rc = launch_group1(cfg, conv, f8, p, batch, st);
     if (rc == -999 && f8 < 3) rc = launch_group2(cfg, conv, f8, p, batch, st);
@@ -81,7 +88,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
                                               {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160},
-                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}, {128, 160}};
+                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}, {128, 160}, {256, 320}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;
@@ -190,8 +197,11 @@ extern "C" int tmix_gemm_fp8(const tmix_gemm_desc* d, const uint8_t* scale_a, co
     return gemm_entry(d, true, scale_a, scale_w, stream);
 }
 
-extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
+static int conv_entry(const tmix_conv_desc* d, const uint8_t* scale_x, const uint8_t* scale_w, void* stream) {
+    const bool fp8 = scale_x != nullptr;
     if (!d || !d->X || !d->Wt || !d->Y) TMIX_FAIL(TMIX_EINVAL, "conv3x3: null descriptor/operand");
+    if (fp8 && (!scale_w || (d->Cin % 128) || d->S1 || d->S2 || (((uintptr_t)scale_x) & 3)))
+        TMIX_FAIL(TMIX_EINVAL, "conv3x3_fp8: needs both scale arrays (scale_x 4-byte aligned), Cin %% 128 == 0 and no shortcut taps");
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: empty problem");
     if (d->Cin % BK) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: Cin=%d must be a multiple of %d", d->Cin, BK);
     if (d->Cout % 4) TMIX_FAIL(TMIX_ESHAPE, "conv3x3: Cout=%d must be a multiple of 4", d->Cout);
@@ -227,8 +237,9 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
         p.ldw = p.K;
     }
     p.epilogue = TMIX_EPI_NONE;
-    p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
-    p.bytesW = (unsigned)((int64_t)d->Cout * p.K * 2);
+    p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * (fp8 ? 1 : 2));
+    p.bytesW = (unsigned)((int64_t)d->Cout * p.K * (fp8 ? 1 : 2));
+    if (fp8) { p.scaleA = scale_x; p.scaleW = scale_w; p.ldScaleA = d->Cin / 32; }
     p.wide = (!getenv("TMIX_NARROW_EPILOGUE") && aligned16(d->Y) && (d->Cout % 8) == 0 && (!d->residual || aligned16(d->residual))) ? 1 : 0;
     if (p.S1 && !p.wide) TMIX_FAIL(TMIX_EALIGN, "conv3x3: shortcut taps need the staged epilogue (16-byte aligned Y, Cout %% 8 == 0)");
     if (d->col_stats_out) {
@@ -237,4 +248,11 @@ extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) {
         p.cs_out = d->col_stats_out;
     }
     return launch(1, p, 1, d->tile_cfg, (hipStream_t)stream);
+}
+
+extern "C" int tmix_conv3x3_nhwc(const tmix_conv_desc* d, void* stream) { return conv_entry(d, nullptr, nullptr, stream); }
+
+extern "C" int tmix_conv3x3_nhwc_fp8(const tmix_conv_desc* d, const uint8_t* scale_x, const uint8_t* scale_w, void* stream) {
+    if (!scale_x) TMIX_FAIL(TMIX_EINVAL, "conv3x3_fp8: null scale array");
+    return conv_entry(d, scale_x, scale_w, stream);
 }

@@ -8,6 +8,7 @@ int launch_group4(int cfg, int conv, int f8, Params& p, int batch, hipStream_t s
     if (conv) return -999;
     // f8: 0 = bf16, 1 = e4m3 with per-row scales, 2 = e4m3 with MX block scales on A
     if (cfg == 16) return f8 == 2 ? launch_cs<256, 256, 2, 4, 4, 0, 0, 3, 1, 0>(p, batch, st) : f8 ? launch_cs<256, 256, 2, 4, 4, 0, 0, 2, 1, 0>(p, batch, st) : launch_cs<256, 256, 2, 4, 4, 0, 0, 1, 1, 0>(p, batch, st);
+    if (cfg == 22 && !f8) return launch_cs<256, 320, 4, 2, 4, 0, 0, 1, 1, 0>(p, batch, st);
     if (cfg == 17) return f8 == 2 ? launch_cs<256, 128, 4, 2, 4, 0, 0, 3, 1, 0>(p, batch, st) : f8 ? launch_cs<256, 128, 4, 2, 4, 0, 0, 2, 1, 0>(p, batch, st) : launch_cs<256, 128, 4, 2, 4, 0, 0, 1, 1, 0>(p, batch, st);
     return -999;
 }

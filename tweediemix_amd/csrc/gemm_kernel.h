@@ -146,8 +146,14 @@ gemm_conv_kernel(const Params p) {
     // alone, 0.45 us for MFMAs + fragment reads alone, 0.56 us together) -- e4m3 halves both.  MX-block A scales (PH = 5) ride in the ring: one more
     // LDS-DMA piece per K-tile, 4 blocks x BM rows of E8M0 bytes behind the W tile of the stage.
     constexpr bool PHL = PH >= 1 && PH <= 3;           // the phase-offset loop
-    static_assert(!PHL || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 128 == 0), "phase-offset mainloop geometry");
-    static_assert(PH <= 3 || (!CONV && KS == 1), "fp8 lock-step loop: plain GEMM");
+    // (tile widths that the eight waves' 16-row LDS-DMA pieces do not divide -- 256 x 320: 20 W pieces -- re-stage the last piece in the surplus slots, like the
+    // lock-step tilings: every wave issues the same count, so the counted waits stay uniform)
+    static_assert(!PHL || (WM * WN == 8 && !LW && !CONV && NS == 4 && BM % 128 == 0 && BN % 32 == 0 && (BM / WM) % 32 == 0 && (BN / WN) % 32 == 0), "phase-offset mainloop geometry");
+    static_assert(PH <= 3 || KS == 1, "fp8 lock-step loop: no in-workgroup split-K");
+    // the convolution on e4m3 operands (PH = 5 only): the input is what a GroupNorm-apply pass wrote as e4m3 with MX block scales in the ROW-major form
+    // [pixels][Cin / 32] (a tap shift then moves a row's scales by a multiple of 4 bytes); a K-tile is 128 channels of one tap, and each staging wave gathers the 4 scale
+    // bytes of its BM / SW rows with one 4-byte LDS-DMA instruction
+    static_assert(!(CONV && PH >= 4) || (PH == 5 && !SC && BM % ((LW ? LW : WM * WN)) == 0 && BM / (LW ? LW : WM * WN) <= 64), "fp8 convolution geometry");
     static_assert(KS == 1 || (KS == 2 && !LW && !PH && !CONV), "in-workgroup split-K geometry");
     static_assert(!SC || (CONV && !LW), "shortcut taps belong to the convolution");
     // PH = 2: the same loop on OCP fp8 (e4m3) operands: a slice row is still 64 bytes, i.e. 64 K values, and the eight
@@ -296,7 +302,8 @@ gemm_conv_kernel(const Params p) {
     // ---- PH: a slice is (BM + BN) rows of 64 bytes; one LDS-DMA instruction covers 16 rows (lane -> row lane >> 2,
     // 16-byte position lane & 3), and position q of row r holds source chunk q ^ ((r >> 2) & 3): the 16-lane service
     // groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then touch 16 distinct 16-byte bank groups.
-    constexpr int PA = PHL ? BM / 16 / NW : 1, PB = PHL ? BN / 16 / NW : 1;      // DMA instructions per wave per slice
+    constexpr int PA = PHL ? BM / 16 / NW : 1, PB = PHL ? (BN / 16 + NW - 1) / NW : 1;      // DMA instructions per wave per slice
+    auto ph_w = [&](int r) { int i = r * NW + w; if constexpr ((BN / 16) % NW != 0) i = min(i, BN / 16 - 1); return i; };     // W piece of this wave's r-th slot
     unsigned phA[PA], phW[PB];
     if constexpr (PHL) {
         const unsigned ch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * (16 / EB));  // swizzled source chunk (elements)
@@ -307,7 +314,7 @@ gemm_conv_kernel(const Params p) {
         }
 #pragma unroll
         for (int r = 0; r < PB; ++r) {
-            int n = n0l + (r * NW + w) * 16 + (lane >> 2); if (n > p.N - 1) n = p.N - 1;
+            int n = n0l + ph_w(r) * 16 + (lane >> 2); if (n > p.N - 1) n = p.N - 1;
             phW[r] = ((unsigned)n * (unsigned)p.ldw + ch) * (unsigned)EB;
         }
     }
@@ -317,17 +324,27 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
         for (int r = 0; r < PA; ++r) blds16(rsA, phA[r], (unsigned)s * 64u, sA + (r * NW + w) * 1024);
 #pragma unroll
-        for (int r = 0; r < PB; ++r) blds16(rsW, phW[r], (unsigned)s * 64u, sW + (r * NW + w) * 1024);
+        for (int r = 0; r < PB; ++r) blds16(rsW, phW[r], (unsigned)s * 64u, sW + ph_w(r) * 1024);
     };
 
     const int nk = p.K / (F8L ? 2 * BK : BK);          // (fp8: a staged row of 128 bytes holds 128 K values)
     int tap = 0, cc = 0;                              // conv K-tile cursor: tap (0..8), 64-channel chunk
-    int cpt = CONV ? p.Cin / BK : 1;                  // (SC: the chunks of the CURRENT tap -- the shortcut taps 9 / 10 have their own channel counts)
+    int cpt = CONV ? p.Cin / (F8L ? 2 * BK : BK) : 1;                  // (SC: the chunks of the CURRENT tap -- the shortcut taps 9 / 10 have their own channel counts)
     const int ntaps_all = SC ? p.ntaps + (p.c1s > 0) + (p.c2s > 0) : p.ntaps;
 
     // conv: the per-lane byte offset of a tap is computed once per tap (when the 64-channel cursor cc wraps);
     // the channel chunk rides in the scalar soffset.  Padding taps get an offset beyond num_records (-> zeros).
     unsigned cvo[RA];
+    constexpr int SRW = (CONV && SCP) ? BM / SW : 1;   // fp8 conv: scale rows this staging wave gathers (row sw_id * SRW + lane)
+    int sb_ = 0, sy_ = 0, sx_ = 0; unsigned scv = 0x80000000u;
+    if constexpr (CONV && SCP) {
+        if (stager) {
+            const int hw = p.Ho * p.Wo;
+            int m = m0l + sw_id * SRW + min(lane, SRW - 1); if (m > p.M - 1) m = p.M - 1;
+            sb_ = m / hw; const int rem = m - sb_ * hw;
+            sy_ = rem / p.Wo; sx_ = rem - sy_ * p.Wo;
+        }
+    }
     auto conv_tap_offsets = [&]() __attribute__((always_inline)) {      // (outlined, it takes the per-row arrays through scratch memory)
         if constexpr (SC) {
             if (tap >= p.ntaps) {                      // shortcut tap: the output pixel itself, Cs channels (stride-1 geometry: H x W = Ho x Wo)
@@ -350,7 +367,16 @@ gemm_conv_kernel(const Params p) {
             else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
                    ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
             const unsigned sw = LW ? swp[r & 1] : (unsigned)asw[LW ? 0 : r];
-            cvo[r] = ok ? (unsigned)(((pb[r] * p.H + iy) * p.Wd + ix) * p.Cin + sw) * 2u : 0x80000000u;
+            cvo[r] = ok ? (unsigned)((pb[r] * p.H + iy) * p.Wd + ix) * (unsigned)p.Cin * (unsigned)EB + sw * 2u : 0x80000000u;
+        }
+        if constexpr (CONV && SCP) {                   // the same tap for this wave's scale rows: byte offset of the row's Cin / 32 scales
+            int iy, ix; bool ok;
+            if (p.mode == TMIX_CONV_S1 || p.mode == TMIX_CONV_T3) { iy = sy_ + ky - 1;     ix = sx_ + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else if (p.mode == TMIX_CONV_S2) { iy = 2 * sy_ + ky - 1; ix = 2 * sx_ + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+            else if (p.mode == TMIX_CONV_S2A) { iy = 2 * sy_ + ky; ix = 2 * sx_ + kx; ok = (iy < p.H) & (ix < p.Wd); }
+            else { const int uy = sy_ + ky - 1, ux = sx_ + kx - 1;
+                   ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
+            scv = ok ? (unsigned)((sb_ * p.H + iy) * p.Wd + ix) * (unsigned)(p.Cin / 32) : 0x80000000u;
         }
     };
     if constexpr (CONV) { if (stager) conv_tap_offsets(); }
@@ -358,15 +384,21 @@ gemm_conv_kernel(const Params p) {
     // fp8 lock-step loop with MX-block A scales: the K-tile's 4 blocks x BM rows of E8M0 bytes as one 1 KB piece behind the W tile -- lane l carries bytes
     // [16 l, 16 l + 16) of it (block 16 l / BM, rows 16 l % BM ..), and staging wave s issues the lanes l % SW == s: one exec-masked instruction per wave,
     // so every staging wave issues the same L instructions per stage (counted vmcnt)
-    const bool sc_mine = SCP && (lane % SW == sw_id) && (16 * lane < 4 * BM);
+    const bool sc_mine = SCP && (CONV ? lane < SRW : (lane % SW == sw_id) && (16 * lane < 4 * BM));
     unsigned sc_voff = 0;
     __amdgpu_buffer_rsrc_t rsSc = rsA;
     if constexpr (SCP) {
-        rsSc = __builtin_amdgcn_make_buffer_rsrc((void*)p.scaleA, 0, (int)((int64_t)(p.K / 32) * p.ldScaleA), 0x00020000);
-        sc_voff = (unsigned)((16 * lane) / BM) * (unsigned)p.ldScaleA + (unsigned)((16 * lane) % BM) + (unsigned)(bz * p.strideScaleA + m0l);
+        if constexpr (CONV) rsSc = __builtin_amdgcn_make_buffer_rsrc((void*)p.scaleA, 0, (int)(p.bytesA / 32), 0x00020000);      // [pixels][Cin / 32]
+        else {
+            rsSc = __builtin_amdgcn_make_buffer_rsrc((void*)p.scaleA, 0, (int)((int64_t)(p.K / 32) * p.ldScaleA), 0x00020000);
+            sc_voff = (unsigned)((16 * lane) / BM) * (unsigned)p.ldScaleA + (unsigned)((16 * lane) % BM) + (unsigned)(bz * p.strideScaleA + m0l);
+        }
     }
     auto scale_piece = [&](char* sA, int kt) __attribute__((always_inline)) {
-        if constexpr (SCP) { if (sc_mine) blds16(rsSc, sc_voff, (unsigned)kt * 4u * (unsigned)p.ldScaleA, sA + A_TILE + B_TILE); }
+        if constexpr (SCP && CONV) {
+            // (kt unused: the cursor (tap, cc) is the conv's own; 4 bytes per row = the K-tile's four MX blocks, rows [sw_id * SRW, + SRW) of the tile)
+            if (sc_mine) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsSc, (__attribute__((address_space(3))) void*)(sA + A_TILE + B_TILE + sw_id * SRW * 4), 4, scv, (unsigned)cc * 4u, 0, 0);
+        } else if constexpr (SCP) { if (sc_mine) blds16(rsSc, sc_voff, (unsigned)kt * 4u * (unsigned)p.ldScaleA, sA + A_TILE + B_TILE); }
     };
     // piece r of this wave's share of K-tile kt (plain GEMM without loader waves): A pieces, W pieces, then the scale piece
     auto dma_piece = [&](const int r, char* sA, int kt) __attribute__((always_inline)) {
@@ -556,7 +588,7 @@ gemm_conv_kernel(const Params p) {
     // residual and C may be the same tensor, so the compiler cannot hoist those loads over the previous chunk's stores): timeline
     // of 4096 x 1280 x 1280 + residual, 128 x 160 tiles: epilogue 8.1 us of a 27.6 us workgroup.  Wave tiles up to 12 pieces.
     constexpr int WP_I = (FN / 2) * 4 + (FN & 1) * 2;          // 16-byte residual pieces per lane per 32-row block
-    constexpr bool WPREF = FM * WP_I <= 12;
+    constexpr bool WPREF = FM * WP_I <= 12 && !(CONV && F8L && LW);      // (the loader-wave fp8 convolution has no registers for it: 16 dwords of scratch otherwise)
     uint4 rw[WPREF ? FM * WP_I : 1];
     const bool wide_res = EK != 1 && WPREF && Rb && (EK >= 2 || (p.wide & 1)) && kg == 0 && !(ABL & 64);
     auto prefetch_residual_wide = [&]() {
@@ -702,7 +734,7 @@ gemm_conv_kernel(const Params p) {
                             if (idx % GAP == (GAP > 1 ? 1 : 0) && issued < PL) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 if (issued < PA) blds16(rsA, phA[issued], (unsigned)(s + 3) * 64u, sA + (issued * NW + w) * 1024);
-                                else             blds16(rsW, phW[issued - PA], (unsigned)(s + 3) * 64u, sW + ((issued - PA) * NW + w) * 1024);
+                                else             blds16(rsW, phW[issued - PA], (unsigned)(s + 3) * 64u, sW + ph_w(issued - PA) * 1024);
                                 __builtin_amdgcn_sched_barrier(0);
                                 ++issued;
                             }
@@ -770,7 +802,8 @@ gemm_conv_kernel(const Params p) {
         }
     };
     auto rdscale = [&](int rbuf, int kk, int i) __attribute__((always_inline)) -> int {
-        return (int)((unsigned)(unsigned char)smem[rbuf * STAGE + A_TILE + B_TILE + (2 * kk + lhi) * BM + wr * TM + i * 32 + l31] * 0x01010101u);
+        if constexpr (CONV) return (int)((unsigned)(unsigned char)smem[rbuf * STAGE + A_TILE + B_TILE + (wr * TM + i * 32 + l31) * 4 + 2 * kk + lhi] * 0x01010101u);
+        else return (int)((unsigned)(unsigned char)smem[rbuf * STAGE + A_TILE + B_TILE + (2 * kk + lhi) * BM + wr * TM + i * 32 + l31] * 0x01010101u);
     };
     auto mma = [&](f32x16& c, const frag_t& b_, const frag_t& a_, int j, int i, int S) __attribute__((always_inline)) {
         if constexpr (ABL & 2) asm volatile("" :: "v"(b_), "v"(a_));
@@ -1534,7 +1567,9 @@ struct TileCfg { int bm, bn; };
 // 18 = tiling 12 (128x160, 4-deep ring) with in-workgroup split-K over two wave groups (KS = 2): eight waves stage, GEMM only
 // 19 / 20 / 21 = tiling 12 (128x160, 4-deep ring) with one / two / FOUR LOADER waves next to the four math waves (GEMM only); with four
 // every SIMD hosts one math wave and one loader, and a K-tile's 36 LDS-DMA instructions are nine per loader
-constexpr int NUM_CFG = 21;
+// 22 = 256x320 with the PHASE-OFFSET mainloop (eight waves of 64x160; bf16 GEMM only): the lock-step 256x320 loop (14) stops all eight waves at every
+// K-tile hand-over -- 79 % of the MFMA rate with the LDS-DMA ablated -- where this one keeps one wave of every SIMD in its MFMA segment
+constexpr int NUM_CFG = 22;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -1568,7 +1603,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CSOK = 1>
 int launch_cs(Params& p, int batch, hipStream_t st) {
     const bool no_trans = p.n_trans_begin < 0;
-    if constexpr (CONV == 1 && !LW) {                 // shortcut taps (validated: stride-1 conv, staged plain epilogue)
+    if constexpr (CONV == 1 && !LW && PH < 4) {       // shortcut taps (validated: stride-1 conv, staged plain epilogue; bf16 only)
         if (p.S1) return p.cs_out ? launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2, 1>(p, batch, st) : launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2, 1>(p, batch, st);
     }
     if constexpr (CSOK) { if (p.cs_out) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2>(p, batch, st); }         // (validated: plain staged epilogue)

@@ -189,9 +189,21 @@ __device__ __forceinline__ float silu_fast(float x) {     // x * sigmoid(x) with
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// maximum over the four lanes of a quad (DPP quad_perm moves): the MX block of the e4m3 form is the 4 adjacent 8-channel vectors of a pixel
+__device__ __forceinline__ float gn_quad_max(float x) {
+    float y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
+    x = fmaxf(x, y);
+    y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));
+    return fmaxf(x, y);
+}
+
+// F8 = 1 (tmix_groupnorm_nhwc_pre_f8): the normalised (+ SiLU) tensor leaves as OCP e4m3 bytes [B*HW][C] with one E8M0 scale per (pixel, 32 channels) in the
+// ROW-major form [B*HW][C / 32] -- the input of tmix_conv3x3_nhwc_fp8 (a tap shift moves a pixel's scales by a multiple of 4 bytes) -- exactly what an MX
+// quantiser makes of the bf16 tensor the plain kernel writes.  Work items are dealt out in multiples of four vectors so that a quad of lanes holds one block.
+template <int F8>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2,
                                                        bf16_t* __restrict__ Y, const float2* __restrict__ ss, int64_t HW, int silu,
-                                                       unsigned long long* prof) {
+                                                       unsigned long long* prof, unsigned char* __restrict__ Y8 = nullptr, unsigned char* __restrict__ S8 = nullptr) {
     __shared__ float2 s_ss[GN_MAX_C];
     const unsigned long long pt0 = (prof && threadIdx.x == 0) ? prof_now() : 0;
     const int C = C1 + C2, nvec = C >> 3;
@@ -199,7 +211,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
     for (int c = tid; c < C; c += 256) s_ss[c] = ss[(int64_t)b * C + c];
     __syncthreads();
     const int64_t total = HW * nvec;
-    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    if (F8) per = (per + 3) & ~(int64_t)3;
     const int64_t i0 = (int64_t)blockIdx.x * per;
     int64_t i1 = i0 + per; if (i1 > total) i1 = total;
     int64_t p = i0 / nvec; int v = (int)(i0 - p * nvec) + tid;      // running (pixel, vector) cursor: no 64-bit division per item
@@ -229,6 +242,21 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
                     if (silu) y = silu_fast(y);
                     f[j] = y;
                 }
+                if constexpr (F8) {
+                    const uint4 pk = pack8(f);
+                    unpack8(pk, f);                       // the bf16-rounded values
+                    float am = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(f[j]));
+                    am = gn_quad_max(am);
+                    const int e = e8m0_for_amax(am);
+                    const float inv = exp2_neg_int(e);
+                    int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, q0, true);
+                    int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, q1, true);
+                    const int64_t row = (int64_t)b * HW + pp[u];
+                    *(uint2*)(Y8 + row * C + cc[u]) = make_uint2((unsigned)q0, (unsigned)q1);
+                    if ((tid & 3) == 0) S8[row * (C >> 5) + (cc[u] >> 5)] = (unsigned char)(e + 127);
+                } else
                 *(uint4*)(Y + ((int64_t)b * HW + pp[u]) * C + cc[u]) = pack8(f);
             }
         }
@@ -549,15 +577,16 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     gn_finalize_kernel<<<dim3(groups, B), 64, 0, st>>>(ws, gamma, beta, ss, C, HW, groups, chunks, eps);
     TMIX_LAUNCH_CHECK();
     int64_t nb = (HW * (C / 8) + GN_APPLY_ITEMS - 1) / GN_APPLY_ITEMS; if (nb < 1) nb = 1; if (nb > GN_APPLY_MAXB) nb = GN_APPLY_MAXB;
-    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);
+    gn_apply_kernel<0><<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
 
-extern "C" int tmix_groupnorm_nhwc_pre(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
-                                       const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
-                                       const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream) {
+static int gn_pre_entry(const void* X1, int C1, const void* X2, int C2, void* Y, void* S8, const float* gamma,
+                        const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                        const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream) {
     if (!X1 || !Y || !gamma || !beta || !ws || !cs1) TMIX_FAIL(TMIX_EINVAL, "groupnorm_pre: null pointer");
+    if (S8 && ((C1 + C2) % 32)) TMIX_FAIL(TMIX_ESHAPE, "groupnorm_pre_f8: C must be a multiple of 32 (MX blocks)");
     if (C2 > 0 && !X2) TMIX_FAIL(TMIX_EINVAL, "groupnorm_pre: C2 > 0 but X2 is null");
     const int C = C1 + C2;
     if (cs1_channels <= 0 || cs2_channels < 0 || cs1_channels + cs2_channels != C || (cs2_channels > 0 && !cs2))
@@ -572,9 +601,23 @@ extern "C" int tmix_groupnorm_nhwc_pre(const void* X1, int C1, const void* X2, i
     gn_finalize_cs_kernel<<<dim3(groups, B), GN_CS_T, 0, st>>>(cs1, cs1_channels, cs2, cs2_channels, gamma, beta, ss, HW, groups, eps, prof);
     TMIX_LAUNCH_CHECK();
     int64_t nb = (HW * (C / 8) + GN_APPLY_ITEMS - 1) / GN_APPLY_ITEMS; if (nb < 1) nb = 1; if (nb > GN_APPLY_MAXB) nb = GN_APPLY_MAXB;
-    gn_apply_kernel<<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);
+    if (S8) gn_apply_kernel<1><<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, nullptr, ss, HW, silu, prof, (unsigned char*)Y, (unsigned char*)S8);
+    else gn_apply_kernel<0><<<dim3((unsigned)nb, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, ss, HW, silu, prof);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
+}
+
+extern "C" int tmix_groupnorm_nhwc_pre(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
+                                       const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                                       const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream) {
+    return gn_pre_entry(X1, C1, X2, C2, Y, nullptr, gamma, beta, ws, B, HW, groups, eps, silu, cs1, cs1_channels, cs2, cs2_channels, stream);
+}
+
+extern "C" int tmix_groupnorm_nhwc_pre_f8(const void* X1, int C1, const void* X2, int C2, void* Y8, void* scales, const float* gamma,
+                                          const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
+                                          const float* cs1, int cs1_channels, const float* cs2, int cs2_channels, void* stream) {
+    if (!scales) TMIX_FAIL(TMIX_EINVAL, "groupnorm_pre_f8: null scale array");
+    return gn_pre_entry(X1, C1, X2, C2, Y8, scales, gamma, beta, ws, B, HW, groups, eps, silu, cs1, cs1_channels, cs2, cs2_channels, stream);
 }
 
 extern "C" int tmix_layernorm(const void* X, void* Y, const float* gamma, const float* beta, int64_t rows, int C,

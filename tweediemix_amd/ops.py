@@ -190,6 +190,17 @@ def quantize_fp8_rows(x, q=None, scale=None):
     _need_cuda(x)
     assert x.dtype == BF16 and x.stride(-1) == 1
     K = x.shape[-1]
+    if K > 8192:                       # rows longer than the kernel keeps in registers (conv weight rows: 9 * Cin): the same arithmetic in torch, once per checkpoint
+        xf = x.float()
+        amax = xf.abs().amax(dim=-1)
+        e = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)).float(), torch.zeros_like(amax)).clamp(-127, 127)
+        qt = (xf * torch.exp2(-e).unsqueeze(-1)).to(torch.float8_e4m3fn).view(torch.uint8)
+        st = (e + 127).to(torch.uint8)
+        if q is not None:
+            q.copy_(qt); qt = q
+        if scale is not None:
+            scale.copy_(st); st = scale
+        return qt.contiguous(), st.contiguous()
     x2 = x.reshape(-1, K)
     if q is None:
         q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
@@ -238,14 +249,15 @@ def gemm_fp8(a8, sa, w8, sw, out=None, a_block_scales=False, f8_out=None, f8_cop
 
 
 def make_conv_desc(x, w, out, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, tile_cfg=0, bias_images=1, col_stats_out=None,
-                   shortcut=None):
+                   shortcut=None, _fp8=False):
     """x [B,H,W,Cin] bf16 NHWC contiguous; w [Cout,3,3,Cin] bf16 contiguous ([Cout,3,Cin] for the temporal CONV_T3,
     where x is [clips, frames, h*w, Cin]).
     shortcut: (s1, s2 or None) -- NHWC tensors whose 1x1 conv_shortcut rides in the same K loop; w is then the 2-d [Cout, 9*Cin + C(s1) + C(s2)]
     matrix [conv taps | shortcut weights] (shortcut_weight) and bias the sum of the two biases."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
-    assert x.dtype == BF16 and w.dtype == BF16 and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
+    dt = torch.uint8 if _fp8 else BF16                  # (e4m3 bytes: tmix_conv3x3_nhwc_fp8)
+    assert x.dtype == dt and w.dtype == dt and x.is_contiguous() and w.is_contiguous() and out.is_contiguous()
     if shortcut is not None:
         s1, s2 = shortcut
         c1, c2 = s1.shape[-1], (0 if s2 is None else s2.shape[-1])
@@ -278,6 +290,22 @@ def shortcut_weight(w_conv, w_sc):
 
 def conv_out_hw(H, W, mode):
     return (H // 2, W // 2) if mode in (L.CONV_S2, L.CONV_S2A) else ((2 * H, 2 * W) if mode == L.CONV_UP2 else (H, W))
+
+
+def conv3x3_fp8(x8, sx, w8, sw, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=12, col_stats_out=None, bias_images=1):
+    """conv3x3 on e4m3 operands (tmix_conv3x3_nhwc_fp8): x8 uint8 [B,H,W,Cin] + sx uint8 [B*H*W, Cin/32] (row-major MX blocks, as groupnorm(f8_out=) writes);
+    w8 uint8 [Cout,3,3,Cin] (or [Cout,3,Cin]) + sw uint8 [Cout] (quantize_fp8_rows over the flattened weight rows)."""
+    _need_cuda(x8, w8, sx, sw)
+    lib = L.load()
+    B, H, W, Cin = x8.shape
+    Ho, Wo = conv_out_hw(H, W, mode)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, w8.shape[0], device=x8.device, dtype=BF16)
+    assert x8.dtype == torch.uint8 and w8.dtype == torch.uint8 and sx.dtype == torch.uint8 and sw.dtype == torch.uint8
+    assert x8.is_contiguous() and w8.is_contiguous() and sx.is_contiguous() and sw.is_contiguous() and sx.numel() == B * H * W * Cin // 32 and sw.numel() == w8.shape[0]
+    d = make_conv_desc(x8, w8, out, bias, batch_bias, residual, mode, tile_cfg, bias_images=bias_images, col_stats_out=col_stats_out, _fp8=True)
+    L.check(lib.tmix_conv3x3_nhwc_fp8(C.byref(d), sx.data_ptr(), sw.data_ptr(), _stream()), "tmix_conv3x3_nhwc_fp8")
+    return out
 
 
 def conv3x3(x, w, bias=None, batch_bias=None, residual=None, mode=L.CONV_S1, out=None, tile_cfg=0, col_stats_out=None, shortcut=None):
@@ -344,7 +372,7 @@ def groupnorm_ws(B, C, groups, device):
     return torch.empty(L.load().tmix_groupnorm_ws_floats(B, C, groups), device=device, dtype=torch.float32)
 
 
-def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=None, ws=None, colstats=None):
+def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=None, ws=None, colstats=None, f8_out=None):
     """x1 [B,HW,C1] (+ optional x2 [B,HW,C2], normalised as channel-concat) bf16 NHWC.
     colstats: (cs1, cs2 or None) -- the column partials the tensor's producers left (colstats_buf; their channel counts add up to C1 + C2 but
     need not be C1 and C2): tmix_groupnorm_nhwc_pre, no statistics pass."""
@@ -353,7 +381,8 @@ def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=Non
     B, HW, C1 = x1.shape[0], x1.numel() // (x1.shape[0] * x1.shape[-1]), x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
     assert x1.is_contiguous() and (x2 is None or x2.is_contiguous()) and gamma.dtype == torch.float32
-    if out is None:
+    assert f8_out is None or colstats is not None, "the e4m3 output exists for the producer-statistics form (tmix_groupnorm_nhwc_pre_f8)"
+    if out is None and f8_out is None:
         out = torch.empty(*x1.shape[:-1], C1 + C2, device=x1.device, dtype=BF16)
     if ws is None:
         ws = groupnorm_ws(B, C1 + C2, groups, x1.device)
@@ -363,6 +392,13 @@ def groupnorm(x1, gamma, beta, groups=32, eps=1e-5, silu=False, x2=None, out=Non
         assert cs1.is_contiguous() and cs1.shape[1] == 2 and (cs2 is None or (cs2.is_contiguous() and cs2.shape[:2] == cs1.shape[:2]))
         if HW % COLSTATS_ROWS == 0:
             assert cs1.shape[0] == B * HW // COLSTATS_ROWS
+        if f8_out is not None:                             # (y8 uint8 [.., C], s8 uint8 [pixels, C / 32]): e4m3 + row-major MX scales instead of bf16
+            y8, s8 = f8_out
+            assert y8.dtype == torch.uint8 and s8.dtype == torch.uint8 and y8.is_contiguous() and s8.is_contiguous()
+            assert y8.numel() == B * HW * (C1 + C2) and s8.numel() == B * HW * (C1 + C2) // 32
+            L.check(lib.tmix_groupnorm_nhwc_pre_f8(_p(x1), C1, _p(x2), C2, _p(y8), _p(s8), _p(gamma), _p(beta), _p(ws), B, HW, groups,
+                                                   float(eps), int(bool(silu)), _p(cs1), ca, _p(cs2), cb, _stream()), "tmix_groupnorm_nhwc_pre_f8")
+            return f8_out
         L.check(lib.tmix_groupnorm_nhwc_pre(_p(x1), C1, _p(x2), C2, _p(out), _p(gamma), _p(beta), _p(ws), B, HW, groups,
                                             float(eps), int(bool(silu)), _p(cs1), ca, _p(cs2), cb, _stream()), "tmix_groupnorm_nhwc_pre")
         return out
