@@ -637,7 +637,9 @@ def main(argv=None):
             other["fp8"] = {"workload": f"{primary} deltas; every projection of every transformer block (attn1 q/k/v, both attention out-projections, attn2 to_q, FF1, "
                                         "FF2: 420 of the 442 GEMM launches) on e4m3 operands with power-of-two scales (tmix_gemm_fp8); no quantiser launch inside a block: "
                                         "the GEMMs that write the residual stream and the attention kernels (tmix_attn_fwd_f8) leave e4m3 + MX-block copies, FF1 -> FF2 "
-                                        "chained through the GEGLU epilogue; proj_in / proj_out, convolutions and the attention inner products stay bf16",
+                                        "chained through the GEGLU epilogue; the ResnetBlock2D convolutions whose K-tile can be 128 channels of one tap and that carry no shortcut taps "
+                                        "(15 of 38) on e4m3 as well (tmix_conv3x3_nhwc_fp8 behind tmix_groupnorm_nhwc_pre_f8); proj_in / proj_out, the other convolutions and the "
+                                        "attention inner products stay bf16",
                             "dtype": "fp8", "value": S_ * args.steps / dt3, "unit": "steps/s", "ms_per_step": 1e3 * dt3 / (args.steps * S_),
                             "parity_check": parity_check(tw3, args, _parts3, primary, device)}
             if rank == 0:

@@ -228,6 +228,7 @@ class I2VPlan(UNetPlan):
         self.fp8_chain_ff = False
         self.fp8_attn_out = False
         self.fp8_tile = 0
+        self.fp8_conv, self.fp8_conv_tile = False, 0
         self._gn_fused = False                           # GroupNorm statistics stay with the statistics kernel here: the temporal norms span 16 frames
                                                          # (86,016 rows per clip, beyond ops.COLSTATS_MAX_HW) and the injection sites rewrite resnet outputs in place
         self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")      # conv_shortcut in conv2's launch, no concat launches (UNetPlan._resnet)

@@ -266,6 +266,8 @@ class UNetWeights:
         ck = (key, None if rows is None else tuple(rows))
         if ck not in self._fp8:
             w = self.t[key]
+            if w.dim() == 4 and rows is None:         # conv weight [Cout, 3, 3, Cin]: one scale per output channel over its 9 * Cin values (tmix_conv3x3_nhwc_fp8)
+                w = w.reshape(w.shape[0], -1)
             if rows is not None and list(rows) != list(range(w.shape[0])):
                 w = w[torch.tensor(list(rows), device=w.device)]
             self._fp8[ck] = ops.quantize_fp8_rows(w.contiguous())
@@ -393,6 +395,8 @@ class UNetPlan:
         self.fp8 = bool(fp8)
         self.fp8_chain_ff = not os.environ.get("TMIX_FP8_FF_ROWS")    # =1: quantise the FF intermediate per row with a separate launch
         self.fp8_attn_out = not os.environ.get("TMIX_FP8_NO_ATTN_OUT")  # =1: attention output in bf16, out-projections on bf16 operands (round 3)
+        self.fp8_conv = not os.environ.get("TMIX_FP8_NO_CONV")         # =1: every convolution on bf16 operands (before round 4's tmix_conv3x3_nhwc_fp8)
+        self.fp8_conv_tile = int(os.environ.get("TMIX_FP8_CONV_TILE", "20"))   # 128 x 160 with two loader waves (12: without)
         self.fp8_tile = int(os.environ.get("TMIX_FP8_TILE", "21"))      # 128 x 160 e4m3 tiling of the N = 1280 / 640 launches (21: loader waves, 12: none, 0: phase-offset only)
         self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
@@ -547,9 +551,24 @@ class UNetPlan:
         owner._cs = ((cs, Cc),)
         return cs
 
-    def _gn(self, x, Cc, HW, name, eps, silu, out=None, x2=None):
-        """x2: a second tensor normalised as the channel-concatenation [x | x2] (Cc counts both)"""
-        out = out if out is not None else self.arena.get(self.B, HW, Cc)
+    def _gn_f8_ok(self, x, Cc, HW, x2=None):
+        """can the GroupNorm over x (| x2) leave its result as e4m3 + row-major MX scales for tmix_conv3x3_nhwc_fp8?  fp8 plans, Cc % 128 == 0, and the
+        statistics must come from the producers (the e4m3 output exists for tmix_groupnorm_nhwc_pre only)"""
+        if not (self.fp8 and getattr(self, "fp8_conv", False)) or Cc % 128 or HW % 32:
+            return False
+        parts = getattr(x, "_cs", None)
+        if x2 is not None:
+            p2 = getattr(x2, "_cs", None)
+            parts = (parts[0], p2[0]) if parts and p2 and len(parts) == 1 and len(p2) == 1 else None
+        return bool(parts) and sum(c for _t, c in parts) == Cc
+
+    def _gn(self, x, Cc, HW, name, eps, silu, out=None, x2=None, f8=False):
+        """x2: a second tensor normalised as the channel-concatenation [x | x2] (Cc counts both).
+        f8 (only when _gn_f8_ok): returns (e4m3 bytes [B, HW, Cc], scales [B * HW, Cc / 32]) instead of the bf16 tensor."""
+        if f8:
+            out = (self.arena.get(self.B, HW, Cc, dtype=torch.uint8), self.arena.get(self.B * HW, Cc // 32, dtype=torch.uint8))
+        else:
+            out = out if out is not None else self.arena.get(self.B, HW, Cc)
         W = self.W
         C2 = 0 if x2 is None else x2.shape[-1]
         parts = getattr(x, "_cs", None)
@@ -558,10 +577,16 @@ class UNetPlan:
             parts = (parts[0], p2[0]) if parts and p2 and len(parts) == 1 and len(p2) == 1 else None
         if parts and sum(c for _t, c in parts) == Cc:
             (cs1, c1), (cs2, c2) = (parts[0], parts[1]) if len(parts) == 2 else (parts[0], (None, 0))
-            self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out.data_ptr(), W[name + ".weight"].data_ptr(),
+            if f8:
+                self._emit(self.lib.tmix_groupnorm_nhwc_pre_f8, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out[0].data_ptr(), out[1].data_ptr(),
+                           W[name + ".weight"].data_ptr(), W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu),
+                           cs1.data_ptr(), c1, cs2.data_ptr() if cs2 is not None else None, c2)
+            else:
+              self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out.data_ptr(), W[name + ".weight"].data_ptr(),
                        W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu),
                        cs1.data_ptr(), c1, cs2.data_ptr() if cs2 is not None else None, c2)
         else:
+            assert not f8
             self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out.data_ptr(), W[name + ".weight"].data_ptr(),
                        W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), self.B, HW, self.cfg.norm_groups, eps, int(silu))
         self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", self.B, HW, Cc))
@@ -656,6 +681,21 @@ class UNetPlan:
         """shortcut: (resnet name, x1, x2 or None) -- the block's input(s), whose 1x1 conv_shortcut rides in this launch's K loop"""
         Ho, Wo = ops.conv_out_hw(Hh, Ww, mode)
         out = self.arena.get(self.B, Ho * Wo, Cout)
+        if isinstance(x, tuple):                        # (e4m3 bytes, row-major MX scales) from _gn(f8=True): tmix_conv3x3_nhwc_fp8
+            assert shortcut is None
+            x8, sx = x
+            w8, sw = self.W.fp8(wname + ".weight")
+            d = ops.make_conv_desc(x8.view(self.B, Hh, Ww, Cin), w8.view(Cout, 3, 3, Cin), out.view(self.B, Ho, Wo, Cout), self.W[wname + ".bias"], batch_bias,
+                                   residual, mode, tile_cfg=self.fp8_conv_tile, bias_images=bias_images,
+                                   col_stats_out=self._colstats(out, self.B * Ho * Wo, Ho * Wo, Cout), _fp8=True)
+            self.keep += [d, x8, sx, w8, sw]
+            self._hint_weights(w8)
+            self._emit(self.lib.tmix_conv3x3_nhwc_fp8, C.byref(d), sx.data_ptr(), sw.data_ptr())
+            fl = 2 * self.B * Ho * Wo * Cout * 9 * Cin
+            self.flops += fl
+            self.launches["conv"].append((d, fl))
+            self.op_meta[len(self.ops) - 1] = ("conv_fp8", fl, d)
+            return out
         w, bias, sc, csc = self.W[wname + ".weight"], self.W[wname + ".bias"], None, 0
         if shortcut is not None:
             w, bias = self.W.conv2_with_shortcut(shortcut[0])
@@ -732,13 +772,30 @@ class UNetPlan:
         tensors, and conv_shortcut's two halves ride in conv2's K loop (only when _sc_ok)"""
         B, W, A = self.B, self.W, self.arena
         HW = Hh * Ww
-        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True, x2=x2)
+        # fp8 plans: norm1 / norm2 leave e4m3 + MX scales and conv1 / conv2 run on e4m3 operands wherever a K-tile can be 128 channels of one tap (Cin % 128 == 0)
+        # and the launch carries no shortcut taps (their sources are raw bf16 tensors)
+        f81 = self._gn_f8_ok(x, Ci, HW, x2)
+        h1 = self._gn(x, Ci, HW, name + ".norm1", 1e-5, True, x2=x2, f8=f81)
         temb, per = self._time_bias(name, Co, emb)
         h2 = self._conv(h1, name + ".conv1", Hh, Ww, Ci, Co, batch_bias=temb, bias_images=per)
-        A.put(h1)
-        h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True)
+        A.put(*h1) if f81 else A.put(h1)
+        sc_fused = self._sc_ok(Ci, Co, x.shape[-1], 0 if x2 is None else x2.shape[-1])
+        f82 = (not sc_fused) and self._gn_f8_ok(h2, Co, HW)
+        h3 = self._gn(h2, Co, HW, name + ".norm2", 1e-5, True, f8=f82)
         A.put(h2)
-        if self._sc_ok(Ci, Co, x.shape[-1], 0 if x2 is None else x2.shape[-1]):
+        if f82:
+            assert x2 is None
+            if Ci != Co:
+                sc = A.get(B, HW, Co)
+                self._gemm(x.view(B * HW, Ci), W[name + ".conv_shortcut.weight"], sc.view(B * HW, Co), bias=W[name + ".conv_shortcut.bias"])
+            else:
+                sc = x
+            out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, residual=sc)
+            A.put(*h3)
+            if Ci != Co:
+                A.put(sc)
+            return out
+        if sc_fused:
             out = self._conv(h3, name + ".conv2", Hh, Ww, Co, Co, shortcut=(name, x, x2))
             A.put(h3)
             return out
