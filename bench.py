@@ -644,6 +644,10 @@ def main(argv=None):
                             "parity_check": parity_check(tw3, args, _parts3, primary, device)}
             if rank == 0:
                 other["fp8"]["roofline"] = fp8_roofline(insitu_profile(tw3))
+            if not args.no_trajectory:                 # the same whole-trajectory / images-per-second measurement on the fp8 plans (every call kind: B = K+1 and B = 2)
+                tr8 = run_trajectories(tw3, args, rank, world, device)
+                other["fp8"].update({"trajectory_steps_per_s": tr8["trajectory_steps_per_s"], "images_per_s": tr8["images_per_s"],
+                                     "single_image_seconds_loop": tr8["single_image"]["seconds_loop"], "cobatch": tr8["cobatch"]})
             del tw3
             torch.cuda.empty_cache()
         if not args.tiny and not args.no_video:
