@@ -67,7 +67,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         if (cfg == 16) cfg = 4;
         else if (cfg == 17) cfg = 2;
         else if (cfg == 22) cfg = 14;
-        else if (cfg >= 18 && (cfg != 20 || p.S1)) cfg = 12;
+        else if (cfg >= 18 && cfg != 20) cfg = 12;
     } else if (cfg == 16 && !f8 && (p.K % 32)) cfg = 4;
     // 256x320 phase-offset: bf16, staged GEGLU / plain epilogues only (the transposed and narrow forms spill at its register count)
     if (!conv && cfg == 22 && (f8 || p.n_trans_begin >= 0 || !(p.epilogue == TMIX_EPI_GEGLU ? (p.wide & 2) : (p.wide & 1)))) cfg = f8 ? 16 : 14;

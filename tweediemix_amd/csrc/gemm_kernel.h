@@ -155,7 +155,7 @@ gemm_conv_kernel(const Params p) {
     // bytes of its BM / SW rows with one 4-byte LDS-DMA instruction
     static_assert(!(CONV && PH >= 4) || (PH == 5 && !SC && BM % ((LW ? LW : WM * WN)) == 0 && BM / (LW ? LW : WM * WN) <= 64), "fp8 convolution geometry");
     static_assert(KS == 1 || (KS == 2 && !LW && !PH && !CONV), "in-workgroup split-K geometry");
-    static_assert(!SC || (CONV && !LW), "shortcut taps belong to the convolution");
+    static_assert(!SC || (CONV && (LW == 0 || LW == 2)), "shortcut taps belong to the convolution (lock-step tilings, with or without two loader waves)");
     // PH = 2: the same loop on OCP fp8 (e4m3) operands: a slice row is still 64 bytes, i.e. 64 K values, and the eight
     // v_mfma_scale_f32_32x32x64_f8f6f4 of a slice do the work of thirty-two bf16 MFMAs in the time of sixteen; every A row and every
     // W row carries ONE power-of-two scale (E8M0 byte) that the instruction applies itself -- constant along K, so a lane loads its
@@ -351,7 +351,7 @@ gemm_conv_kernel(const Params p) {
                 const int Cs = tap == p.ntaps ? p.c1s : p.c2s;
 #pragma unroll
                 for (int r = 0; r < RA; ++r)
-                    cvo[r] = (unsigned)(((pb[r] * p.H + py[r]) * p.Wd + px[r]) * Cs + asw[r]) * 2u;
+                    cvo[r] = (unsigned)(((pb[r] * p.H + py[r]) * p.Wd + px[r]) * Cs + (LW ? (int)swp[r & 1] : asw[LW ? 0 : r])) * 2u;
                 cpt = Cs / BK;
                 return;
             }
@@ -1603,7 +1603,7 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CSOK = 1>
 int launch_cs(Params& p, int batch, hipStream_t st) {
     const bool no_trans = p.n_trans_begin < 0;
-    if constexpr (CONV == 1 && !LW && PH < 4) {       // shortcut taps (validated: stride-1 conv, staged plain epilogue; bf16 only)
+    if constexpr (CONV == 1 && (LW == 0 || LW == 2) && PH < 4) {       // shortcut taps (validated: stride-1 conv, staged plain epilogue; bf16 only)
         if (p.S1) return p.cs_out ? launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2, 1>(p, batch, st) : launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 0, 2, 1>(p, batch, st);
     }
     if constexpr (CSOK) { if (p.cs_out) return launch_cfg<BM, BN, WM, WN, NS, CONV, LW, PH, KS, 1, 2>(p, batch, st); }         // (validated: plain staged epilogue)

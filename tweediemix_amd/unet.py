@@ -496,7 +496,7 @@ class UNetPlan:
             for _rep in range(reps):
                 for cfg in cands:
                     for _i, kind, d in tun:
-                        d.tile_cfg = cfg if kind == "gemm" else (12 if (cfg == 20 and d.S1) else conv_alias.get(cfg, cfg))   # (shortcut taps: no loader-wave kernel)
+                        d.tile_cfg = cfg if kind == "gemm" else conv_alias.get(cfg, cfg)
                     self._link_ln()
                     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in tun]
                     for i, (fn, args) in enumerate(self.ops):
@@ -516,8 +516,6 @@ class UNetPlan:
                         best_t[(k, cfg)] = min(best_t.get((k, cfg), float("inf")), t)
             for k in set(keys):
                 ok = [c for c in cands if k.startswith("('gemm'") or c not in conv_alias]
-                if k.startswith("('conv'") and len(eval(k)) == 8:      # with shortcut taps tiling 20 runs as 12: one candidate, not two
-                    ok = [c for c in ok if c != 20]
                 if k not in _TUNE_CACHE:
                     _TUNE_CACHE[k] = min(ok, key=lambda c: best_t[(k, c)])
                 if SHARED + k not in _TUNE_CACHE:     # starting point for chains that share the chip (refine_group re-ranks under load)
