@@ -99,4 +99,21 @@ def test_argument_errors_are_reported_before_any_launch():
     d.M, d.N, d.K, d.batch, d.lda, d.ldw, d.ldc, d.n_trans_begin = 256, 256, 256, 1, 256, 256, 256, -1
     assert l.tmix_gemm_fp8(C.byref(d), C.cast(C.c_void_p(0x5000), C.POINTER(C.c_uint8)), C.cast(C.c_void_p(0x6000), C.POINTER(C.c_uint8)), None) == lib.EINVAL
     assert b"col_stats_out" in l.tmix_last_error_string()
+    # round 4 entry points: the e4m3 forms validate before touching the device
+    assert l.tmix_attn_fwd_f8(fake, 64, 64, fake, 64, 64, fake, 80, 64 * 80, fake, 64, None, 64, 1, 1, 64, 77, 0.125, None) == lib.EINVAL          # no scale array
+    assert l.tmix_attn_fwd_f8(fake, 64, 64, fake, 64, 64, fake, 80, 64 * 80, fake, 32, fake, 64, 1, 1, 64, 77, 0.125, None) == lib.EINVAL          # rows narrower than H * 64
+    cd = lib.ConvDesc()
+    cd.X, cd.Wt, cd.Y = 0x1000, 0x2000, 0x3000
+    cd.B, cd.H, cd.W, cd.Cin, cd.Cout = 1, 8, 8, 64, 64
+    assert l.tmix_conv3x3_nhwc_fp8(C.byref(cd), C.c_void_p(0x4000), C.c_void_p(0x5000), None) == lib.EINVAL and b"128" in l.tmix_last_error_string()   # Cin % 128
+    cd.Cin = 128
+    assert l.tmix_conv3x3_nhwc_fp8(C.byref(cd), None, C.c_void_p(0x5000), None) == lib.EINVAL
+    assert l.tmix_groupnorm_nhwc_pre_f8(fake, 48, None, 0, fake, fake, fake, fake, fake, 1, 64, 3, 1e-5, 1, fake, 48, None, 0, None) == lib.ESHAPE     # C % 32
+    assert l.tmix_groupnorm_nhwc_pre_f8(fake, 64, None, 0, fake, None, fake, fake, fake, 1, 64, 32, 1e-5, 1, fake, 64, None, 0, None) == lib.EINVAL    # no scales
+    d = lib.GemmDesc()
+    d.A, d.W, d.C, d.Ct = 0x1000, 0x2000, 0x3000, 0x4000
+    d.M, d.N, d.K, d.batch, d.lda, d.ldw, d.ldc, d.ldct, d.n_trans_begin, d.epilogue = 256, 1280, 256, 1, 256, 256, 640, 256, -1, lib.EPI_GEGLU
+    d.tile_cfg, d.reserved0 = 21, lib.F8_GEGLU_OUT
+    u8 = lambda a: C.cast(C.c_void_p(a), C.POINTER(C.c_uint8))
+    assert l.tmix_gemm_fp8(C.byref(d), u8(0x5000), u8(0x6000), None) == lib.EINVAL and b"tile_cfg" in l.tmix_last_error_string()     # 160-wide tiles cannot end MX blocks of the GEGLU output
 
