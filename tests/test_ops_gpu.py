@@ -806,7 +806,7 @@ def test_fp8_row_quantizer_matches_torch_float8(ops, rows, K):
     assert float((back - xf).abs().max() / xf.abs().max()) < 2 ** -3   # 3 mantissa bits
 
 
-@pytest.mark.parametrize("tile", [0, 12, 16, 17, 21])       # 12 / 21: e4m3 in the lock-step loops (128 x 160 without / with loader waves)
+@pytest.mark.parametrize("tile", [0, 12, 16, 17, 19, 20, 21])       # 12 / 19 / 20 / 21: e4m3 in the lock-step loops (128 x 160 without / with 1, 2, 4 loader waves)
 @pytest.mark.parametrize("M,N,K,kw", [(512, 512, 256, {}), (1024, 1280, 1280, {"bias": True, "residual": True}),
                                       (300, 264, 128, {"bias": True}), (2048, 2560, 1280, {"geglu": True}),
                                       (1024, 3840, 1280, {"trans": True, "batch": 2})])
@@ -861,7 +861,7 @@ def _mx_quantize(x):
                                                                         * torch.exp2(e).unsqueeze(2)).view(rows, K)
 
 
-@pytest.mark.parametrize("tile", [12, 16, 17, 21])
+@pytest.mark.parametrize("tile", [12, 16, 17, 19, 20, 21])
 @pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1024, 1280, 5120), (300, 264, 128)])
 def test_gemm_fp8_with_mx_block_scales_on_a(ops, tile, M, N, K):
     """TMIX_F8_A_BLOCK_SCALES: one E8M0 scale per 32 K values of every A row, kept in LDS for the K loop (lane half h of a 64-wide
@@ -936,7 +936,7 @@ def test_gemm_leaves_an_e4m3_copy_of_its_output_for_the_next_gemm(ops, tile, bat
         ops.gemm(a[:, :150].contiguous(), w, tile_cfg=tile, f8_copy=ops.F8Copy(batch * 150, N, "cuda"))
 
 
-@pytest.mark.parametrize("tile", [12, 21])
+@pytest.mark.parametrize("tile", [12, 19, 20, 21])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_gemm_fp8_lockstep_tilings_leave_copy_and_statistics(ops, tile, batch):
     """the N = 1280 GEMMs of an fp8 plan (attention out-projections, FF2) on e4m3 operands in the 128 x 160 loops: bf16 rows + residual, LayerNorm row

@@ -31,7 +31,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12, 12};
         // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
         if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
-        if (!(cfg == 21 && !conv && p.scaleA && p.K % 128 == 0)) cfg = alt[cfg];      // (tiling 21 on e4m3 operands carries the copy itself)
+        if (!((cfg == 19 || cfg == 20 || cfg == 21) && !conv && p.scaleA && p.K % 128 == 0)) cfg = alt[cfg];      // (the loader-wave tilings on e4m3 operands carry the copy themselves)
     }
     int f8 = 0;
     if (!conv && p.scaleA) {     // fp8 operands (tmix_gemm_fp8): the phase-offset loop only; 256x128 tiles for narrow N
@@ -40,14 +40,15 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         // the lock-step loops on e4m3 operands (128 x 160 with / without loader waves, 256 x 320): rows of 128 K values
         // (not for the e4m3 GEGLU output: its MX blocks of 32 output columns need wave tiles that are multiples of 64 weight rows wide -- the
         // phase-offset tilings' 128 x 64; a 160-wide tile ends in the middle of a block)
-        if ((cfg == 12 || cfg == 21) && p.K % 128 == 0 && !p.f8out) {
+        if ((cfg == 12 || cfg == 19 || cfg == 20 || cfg == 21) && p.K % 128 == 0 && !p.f8out) {
             f8 += 2;
             // the loader-wave instantiation at the 256-register limit of two waves per SIMD holds the staged plain / GEGLU epilogues only (the transposed and
             // narrow forms spill there, and scratch traffic would break the counted vmcnt): those launches run without loader waves
             const bool staged = p.n_trans_begin < 0 && (p.epilogue == TMIX_EPI_GEGLU ? (p.wide & 2) : (p.wide & 1));
-            if (cfg == 21 && !staged) cfg = 12;
+            const bool lw = cfg != 12;
+            if (lw && !staged) cfg = 12;
             // ... and the e4m3 copy of C in its straight-line form only (epilogue family 4: bf16 output, no activation, no row-group bias)
-            if (cfg == 21 && p.f8copy && (p.epilogue != TMIX_EPI_NONE || p.rgb)) cfg = 12;
+            if (lw && p.f8copy && (p.epilogue != TMIX_EPI_NONE || p.rgb)) cfg = 12;
         } else
         cfg = (cfg == 17 || (cfg != 16 && (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch < 160)) ? 17 : 16;
         if (f8 == 2 && cfg == 16 && p.K / 32 > f8_block_cap(256)) cfg = 17;    // the tile's block scales stay in LDS beside the ring
@@ -136,9 +137,9 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     p.bytesA = (unsigned)(((int64_t)(d->M - 1) * d->lda + d->K) * el);
     p.bytesW = (unsigned)(((int64_t)(d->N - 1) * d->ldw + d->K) * el);
     if (fp8) {
-        const bool lockstep = (d->tile_cfg == 12 || d->tile_cfg == 21) && d->K % 128 == 0 && !(d->reserved0 & TMIX_F8_GEGLU_OUT);
+        const bool lockstep = (d->tile_cfg == 12 || (d->tile_cfg >= 19 && d->tile_cfg <= 21)) && d->K % 128 == 0 && !(d->reserved0 & TMIX_F8_GEGLU_OUT);
         if (d->tile_cfg != TMIX_TILE_AUTO && d->tile_cfg != 16 && d->tile_cfg != 17 && !lockstep)
-            TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg must be AUTO, 16 (256x256), 17 (256x128) or -- K %% 128 == 0, no e4m3 GEGLU output -- 12 / 21 (128x160 without / with loader waves)");
+            TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg must be AUTO, 16 (256x256), 17 (256x128) or -- K %% 128 == 0, no e4m3 GEGLU output -- 12 / 19 / 20 / 21 (128x160 without / with one, two, four loader waves)");
         p.scaleA = scaleA; p.scaleW = scaleW; p.strideScaleA = d->strideA ? d->M : 0; p.strideScaleW = d->strideW ? d->N : 0;
         if (d->reserved0 & TMIX_F8_A_BLOCK_SCALES) {
             p.ldScaleA = (int64_t)d->batch * d->M;                                                // [K/32][batch * M], dense

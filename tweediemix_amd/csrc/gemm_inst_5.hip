@@ -12,6 +12,8 @@ int launch_group5(int cfg, int conv, int f8, Params& p, int batch, hipStream_t s
     }
     // f8: 3 = one E8M0 scale per A row, 4 = MX block scales on A (one more LDS-DMA piece per K-tile)
     if (cfg == 12) return f8 == 4 ? launch_cs<128, 160, 4, 1, 4, 0, 0, 5, 1, 0>(p, batch, st) : launch_cs<128, 160, 4, 1, 4, 0, 0, 4, 1, 0>(p, batch, st);
+    if (cfg == 19) return f8 == 4 ? launch_cs<128, 160, 4, 1, 3, 0, 1, 5, 1, 0>(p, batch, st) : launch_cs<128, 160, 4, 1, 3, 0, 1, 4, 1, 0>(p, batch, st);
+    if (cfg == 20) return f8 == 4 ? launch_cs<128, 160, 4, 1, 4, 0, 2, 5, 1, 0>(p, batch, st) : launch_cs<128, 160, 4, 1, 4, 0, 2, 4, 1, 0>(p, batch, st);
     if (cfg == 21) return f8 == 4 ? launch_cs<128, 160, 4, 1, 4, 0, 4, 5, 1, 0>(p, batch, st) : launch_cs<128, 160, 4, 1, 4, 0, 4, 4, 1, 0>(p, batch, st);
     return -999;
 }
