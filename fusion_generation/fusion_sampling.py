@@ -82,6 +82,8 @@ def build_parser():
     p.add_argument('--streams', type=int, default=1, help='launch chains per UNet call (2: batch rows split over two HIP streams)')
     p.add_argument('--lora_mode', type=str, default='merged', choices=['merged', 'lowrank'],
                    help='LoRA deltas as merged per-concept weight sets (default, fastest) or in the reference\'s own low-rank form up(down(x)) (no weight copies)')
+    p.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'fp8'],
+                   help='fp8: the transformer blocks\' projections, the attention outputs and the eligible ResnetBlock2D convolutions on e4m3 operands with power-of-two block scales (merged LoRA only)')
     p.add_argument('--no_graphs', action='store_true')
     p.add_argument('--tiny', action='store_true', help='tiny UNet config (smoke tests)')
     return p
@@ -121,6 +123,8 @@ def noise_for_seed(seed, h, w):
 
 def main(argv=None):
     opt = build_parser().parse_args(argv)
+    if opt.dtype == 'fp8' and opt.lora_mode == 'lowrank':
+        raise SystemExit('--dtype fp8 quantises the merged per-concept projection weights: use --lora_mode merged')
     from tweediemix_amd import dist as D, launch as LA, masks as M, sampler as S, unet as U, weights as Wt
     if opt.gpus > 1 and not LA.launched():
         return LA.self_launch(opt.gpus)
@@ -209,7 +213,8 @@ def main(argv=None):
         return M.build_masks(M.random_rectangle_masks(K, opt.resolution_h, opt.resolution_w, seed=sd_), h, w, opt.device)
 
     tw = S.Tweediemix(opt, W, te, ts, provider, concept_num=K, lora=LORA,
-                      strict_reference=strict, use_graphs=not opt.no_graphs, n_seeds=per, n_streams=opt.streams, vae=vae)
+                      strict_reference=strict, use_graphs=not opt.no_graphs, n_seeds=per, n_streams=opt.streams, vae=vae,
+                      fp8=(opt.dtype == 'fp8'))
     if vae_scaling:                                       # fusion_sampling.py:518 divides by vae.config.scaling_factor
         tw.vae_scaling_factor = float(vae_scaling)
     if sidecar and vae is not None:

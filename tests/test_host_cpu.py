@@ -2,6 +2,7 @@
 vectors, parameter inventories, CLI flag surface, tile/plan bookkeeping."""
 import os
 
+import pytest
 import numpy as np
 import torch
 
@@ -57,6 +58,10 @@ def test_cli_flag_surface():
     fs.LORA = True
     assert fs.build_parser().parse_args([]).t_stop == 0.9
     fs.LORA = False
+    # additive flags: default arithmetic is bf16, e4m3 operands only on request
+    assert opt.dtype == 'bf16' and fs.build_parser().parse_args(['--dtype', 'fp8']).dtype == 'fp8'
+    with pytest.raises(SystemExit):
+        fs.build_parser().parse_args(['--dtype', 'fp16'])
 
 
 def test_geglu_interleave_is_a_permutation():

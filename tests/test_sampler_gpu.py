@@ -224,6 +224,11 @@ def test_cli_drop_in_flags(tmp_path):
     lat2 = fs.main(argv + ["--t_stop", "0.8"])
     fs.LORA = False
     assert torch.isfinite(lat2).all()
+    # --dtype fp8 (additive): same trajectory with the projections on e4m3 operands; a 3-level toy UNet through ~10 free-running
+    # steps only has to stay finite and near the bf16 latent (the per-call bound is tests/test_unet_gpu.py's)
+    lat8 = fs.main(argv + ['--dtype', 'fp8'])
+    assert lat8.shape == lat.shape and torch.isfinite(lat8).all()
+    assert (lat8.float() - lat.float()).norm() / lat.float().norm() <= 0.3
 
 
 def test_sidecar_file_contract_and_decode(tmp_path):
