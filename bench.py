@@ -164,13 +164,14 @@ def parity_check(tw, args, parts, kind, device):
 
 
 # ------------------------------------------------------------------------------------------------ in-situ roofline
-def insitu_profile(tw, reps=3):
-    """per-launch device-clock timing of the captured fusion step, in the schedule the timed region replays.
+def insitu_profile(tw, reps=3, kind="fusion", mode=None):
+    """per-launch device-clock timing of the captured fusion step (or of another call kind: tools/step_shapes.py), in the schedule the timed region replays.
     Returns per-class totals of the median replay: launches, sum of launch durations, union busy time, flops."""
     import collections
     from tweediemix_amd import lib as L
     lib = L.load()
-    plan = tw.plan("fusion")
+    mode = L.STEP_FUSION if mode is None else mode
+    plan = tw.plan(kind)
     meta = plan.issued_meta()
     n = len(meta)
     slots = torch.zeros(n, 8, dtype=torch.int64, device=tw.device)
@@ -182,7 +183,7 @@ def insitu_profile(tw, reps=3):
         if tw.use_graphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                tw._enqueue_step("fusion", L.STEP_FUSION)
+                tw._enqueue_step(kind, mode)
             run = g.replay
         else:
             run = None
@@ -191,17 +192,17 @@ def insitu_profile(tw, reps=3):
     if run is None:                                     # eager mode: instrument every run
         def run():
             lib.tmix_prof_begin(slots.data_ptr(), n, 0)
-            tw._enqueue_step("fusion", L.STEP_FUSION)
+            tw._enqueue_step(kind, mode)
             lib.tmix_prof_end()
     else:
         assert used == n, (used, n)
     plain_ms = None
-    if tw.use_graphs and ("fusion", L.STEP_FUSION) in tw.graphs:      # the un-instrumented graph the timed region replays, same moment
+    if tw.use_graphs and (kind, mode) in tw.graphs:      # the un-instrumented graph the timed region replays, same moment
         ts_ = []
         for _ in range(reps + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tw.graphs[("fusion", L.STEP_FUSION)].replay()
+            tw.graphs[(kind, mode)].replay()
             e1.record()
             torch.cuda.synchronize()
             ts_.append(e0.elapsed_time(e1))

@@ -330,6 +330,26 @@ int tmix_linear_small(const float* in, const void* W, const float* bias, const f
 int tmix_linear_small_sections(const float* in, const void* W, const float* bias, float* out, int M, int N, int K,
                                int act_in, const int* sec_starts, int nsec, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sample-independent half of I2VGenXLUNet.forward (BASELINE config #5): the fps embedding, the context tokens and the image-latent
+ * features that video_gen/pipeline_i2vgen_xl.py:604-639 prepares and :688-697 passes to the UNet on every step are constant over the
+ * loop; tweediemix_amd/i2vgen.py conditioning() evaluates them once per video on these fp32 kernels (layers of 4 .. 64 channels).
+ * 3x3 convolution, padding 1, stride 1 or 2: x fp32 NCHW [B,Cin,H,W], w fp32 OIHW [Cout,Cin,3,3] (the checkpoint's layout),
+ * y fp32 NCHW [B,Cout,(H-1)/stride+1,(W-1)/stride+1]; silu != 0 applies SiLU to the result. */
+int tmix_conv3x3_f32(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nchw, int B, int Cin, int H, int W, int Cout,
+                     int stride, int silu, void* stream);
+/* torch.nn.AdaptiveAvgPool2d((OH, OW)) over `planes` fp32 [H][W] planes: window i = [floor(i H / OH), ceil((i + 1) H / OH)). */
+int tmix_adaptive_avgpool_f32(const float* x, float* y, int64_t planes, int H, int W, int OH, int OW, void* stream);
+/* out[M,N] = act_out(act_in(in[M,K]) W[N,K]^T + bias), everything fp32 (act: 0 none, 1 SiLU), M <= 256. */
+int tmix_linear_f32(const float* in, const float* W, const float* bias, float* out, int M, int N, int K, int act_in, int act_out, void* stream);
+/* image_latents_temporal_encoder (diffusers I2VGenXLTransformerTemporalEncoder, width `channels` = 4): per (clip, pixel) over its <= 16 frames
+ *   x1 = x + to_out(attention(LayerNorm(x)))  (two heads of 4, scale 1/2),   y = x1 + W2 gelu(W1 x1 + b1) + b2
+ * x fp32 [clips*frames, 4, H, W] (the output of image_latents_proj_in), y fp32 [clips, 4, frames, H, W] (what the UNet concatenates to the
+ * sample); weights fp32 in the checkpoint's [out, in] layout: wq / wk / wv [8,4], wo [4,8], w1 [16,4], w2 [4,16]. */
+int tmix_i2v_temporal_encoder(const float* x, float* y, int clips, int frames, int channels, int64_t hw, const float* ln_gamma, const float* ln_beta,
+                              const float* wq, const float* wk, const float* wv, const float* wo, const float* bo,
+                              const float* w1, const float* b1, const float* w2, const float* b2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,3 +117,11 @@ def test_argument_errors_are_reported_before_any_launch():
     u8 = lambda a: C.cast(C.c_void_p(a), C.POINTER(C.c_uint8))
     assert l.tmix_gemm_fp8(C.byref(d), u8(0x5000), u8(0x6000), None) == lib.EINVAL and b"tile_cfg" in l.tmix_last_error_string()     # 160-wide tiles cannot end MX blocks of the GEGLU output
 
+    # the once-per-video conditioning kernels of the I2VGen-XL path (csrc/conditioning.hip)
+    assert l.tmix_conv3x3_f32(fake, fake, None, fake, 1, 4, 8, 8, 16, 3, 0, None) == lib.ESHAPE and b"stride" in l.tmix_last_error_string()
+    assert l.tmix_conv3x3_f32(fake, None, None, fake, 1, 4, 8, 8, 16, 1, 0, None) == lib.EINVAL
+    assert l.tmix_adaptive_avgpool_f32(fake, fake, 4, 8, 8, 0, 4, None) == lib.ESHAPE
+    assert l.tmix_linear_f32(fake, fake, None, fake, 257, 8, 8, 0, 0, None) == lib.ESHAPE
+    assert l.tmix_i2v_temporal_encoder(fake, fake, 1, 16, 8, 64, *([fake] * 11), None) == lib.ESHAPE and b"channels" in l.tmix_last_error_string()
+    assert l.tmix_i2v_temporal_encoder(fake, fake, 1, 17, 4, 64, *([fake] * 11), None) == lib.ESHAPE and b"frames" in l.tmix_last_error_string()
+    assert l.tmix_i2v_temporal_encoder(fake, fake, 1, 16, 4, 64, *([fake] * 10), None, None) == lib.EINVAL

@@ -223,3 +223,86 @@ def test_plan_group_equals_single_plan():
         b = grp(sample, 701).clone()
         torch.cuda.synchronize()
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the once-per-video conditioning kernels (csrc/conditioning.hip), each against the torch op it stands for, fp32
+@pytest.mark.parametrize("B,Ci,H,W,Co,stride,silu", [(2, 4, 16, 8, 16, 1, True), (3, 16, 13, 9, 20, 1, False), (2, 32, 32, 32, 64, 2, True),
+                                                     (2, 64, 16, 16, 96, 2, False), (1, 5, 7, 11, 3, 2, True), (32, 4, 56, 96, 16, 1, True)])
+def test_conv3x3_f32_matches_torch(B, Ci, H, W, Co, stride, silu):
+    import torch.nn.functional as F
+    from tweediemix_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Ci)
+    x, w, b = torch.randn(B, Ci, H, W, generator=g).cuda(), (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).cuda(), torch.randn(Co, generator=g).cuda()
+    got = ops.conv3x3_f32(x, w, b, stride=stride, silu=silu)
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    want = F.silu(want) if silu else want
+    assert got.shape == want.shape and rel(got, want.float()) < 2e-6, rel(got, want.float())
+    got0 = ops.conv3x3_f32(x, w, None, stride=stride)                  # no bias
+    assert rel(got0, F.conv2d(x.double(), w.double(), None, stride=stride, padding=1).float()) < 2e-6
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(56, 96, 32, 32), (16, 8, 8, 8), (7, 5, 3, 4), (8, 8, 8, 8), (5, 5, 7, 9)])
+def test_adaptive_avgpool_f32_matches_torch(H, W, oh, ow):
+    import torch.nn.functional as F
+    from tweediemix_amd import ops
+    x = torch.randn(2, 6, H, W, generator=torch.Generator().manual_seed(H * W)).cuda()
+    got = ops.adaptive_avgpool_f32(x, oh, ow)
+    assert got.shape == (2, 6, oh, ow) and (got - F.adaptive_avg_pool2d(x, (oh, ow))).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(2, 1280, 320), (2, 4096, 1280), (20, 37, 19), (1, 5, 1024)])
+def test_linear_f32_matches_torch(M, N, K):
+    import torch.nn.functional as F
+    from tweediemix_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) / K ** 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    assert rel(ops.linear_f32(x, w, b), F.linear(x.double(), w.double(), b.double()).float()) < 2e-6
+    want = F.silu(F.linear(F.silu(x.double()), w.double(), b.double())).float()
+    assert rel(ops.linear_f32(x, w, b, act_in=True, act_out=True), want) < 2e-6
+    assert rel(ops.linear_f32(x, w), F.linear(x.double(), w.double()).float()) < 2e-6
+
+
+@pytest.mark.parametrize("clips,frames,H,W", [(2, 16, 16, 8), (1, 9, 5, 7), (2, 16, 56, 96), (3, 1, 4, 4)])
+def test_i2v_temporal_encoder_matches_torch(clips, frames, H, W):
+    """the fused image_latents_temporal_encoder launch against the block written out in torch (LayerNorm, two heads of 4 over the frames,
+    out-projection + residual, exact-GELU feed-forward + residual; I2VGenXLTransformerTemporalEncoder), fp64 reference."""
+    import torch.nn.functional as F
+    from tweediemix_amd import ops
+    g = torch.Generator().manual_seed(clips * 7 + frames)
+    C_ = 4
+    n = "e"
+    shapes = {".norm1.weight": (C_,), ".norm1.bias": (C_,), ".attn1.to_q.weight": (2 * C_, C_), ".attn1.to_k.weight": (2 * C_, C_), ".attn1.to_v.weight": (2 * C_, C_),
+              ".attn1.to_out.0.weight": (C_, 2 * C_), ".attn1.to_out.0.bias": (C_,), ".ff.net.0.proj.weight": (4 * C_, C_), ".ff.net.0.proj.bias": (4 * C_,),
+              ".ff.net.2.weight": (C_, 4 * C_), ".ff.net.2.bias": (C_,)}
+    p = {n + k: (torch.randn(*s, generator=g) * (1.0 if len(s) == 1 else 0.7)).cuda() for k, s in shapes.items()}
+    x = (torch.randn(clips * frames, C_, H, W, generator=g) * 2 + 0.5).cuda()
+    got = ops.i2v_temporal_encoder(x, clips, frames, p, n)
+    d = {k: v.double() for k, v in p.items()}
+    t = x.double().view(clips, frames, C_, H, W).permute(0, 3, 4, 1, 2).reshape(clips * H * W, frames, C_)
+    h = F.layer_norm(t, (C_,), d[n + ".norm1.weight"], d[n + ".norm1.bias"], 1e-5)
+    q, k, v = [F.linear(h, d[n + f".attn1.to_{c}.weight"]).view(-1, frames, 2, C_).transpose(1, 2) for c in "qkv"]
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(-1, frames, 2 * C_)
+    t = t + F.linear(o, d[n + ".attn1.to_out.0.weight"], d[n + ".attn1.to_out.0.bias"])
+    t = t + F.linear(F.gelu(F.linear(t, d[n + ".ff.net.0.proj.weight"], d[n + ".ff.net.0.proj.bias"])), d[n + ".ff.net.2.weight"], d[n + ".ff.net.2.bias"])
+    want = t.view(clips, H, W, frames, C_).permute(0, 4, 3, 1, 2).float()
+    assert got.shape == want.shape == (clips, C_, frames, H, W) and rel(got, want) < 1e-5, rel(got, want)
+
+
+def test_conditioning_runs_on_the_library_only(monkeypatch):
+    """conditioning() must not reach MIOpen / SDPA: the torch functional ops it used to call raise while it runs, and the result still
+    matches the oracle."""
+    import torch.nn.functional as F
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I
+    B, Fr, H, W, Lk = 2, 16, 16, 8, 13
+    sd, il, emb, ehs, fps, sample = _setup(IO.TINY, I.TINY, B, Fr, H, W, Lk)
+    Wt = I.I2VWeights(I.TINY, sd)
+    fe_o, ctx_o, ilf_o = IO.conditioning(sd, IO.TINY, fps, il, emb, ehs)
+
+    def boom(*a, **k):
+        raise AssertionError("conditioning() called a torch functional op")
+    for name in ("conv2d", "linear", "scaled_dot_product_attention", "layer_norm", "adaptive_avg_pool2d", "gelu", "silu"):
+        monkeypatch.setattr(F, name, boom)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    assert rel(fe, fe_o) < 1e-4 and rel(ctx, ctx_o) < 1e-4 and rel(ilf, ilf_o) < 1e-4

@@ -4,7 +4,7 @@ K/V, GroupNorm, implicit-GEMM convs) with the frames folded into the batch; the 
 GroupNorm kernels over the frame axis plus `TMIX_CONV_T3` (TemporalConvLayer) and `tmix_temporal_attn`
 (TransformerTemporalModel).  Everything that does not depend on the sample or the timestep (fps / context / image-latent
 embeddings: a handful of 4..64-channel convolutions and one 4-wide temporal encoder) is evaluated ONCE per video by
-`conditioning()` below with stock torch ops -- init-time, outside the per-step path.
+`conditioning()` below on the library's fp32 kernels (csrc/conditioning.hip) -- init-time, outside the per-step path.
 
 PARITY UNPINNED (diffusers is neither vendored in the reference nor installed here; no checkpoint offline): structure and
 key names follow the published `I2VGenXLUNet`; the restated inventory has 1,420,469,224 parameters = 2.84 GB in fp16, the
@@ -16,7 +16,6 @@ import os
 from dataclasses import dataclass
 
 import torch
-import torch.nn.functional as F
 
 from . import lib as L
 from . import ops
@@ -133,41 +132,31 @@ class I2VWeights:
 
 @torch.no_grad()
 def conditioning(W: I2VWeights, fps, image_latents, image_embeddings, encoder_hidden_states):
-    """the sample- and timestep-independent part of I2VGenXLUNet.forward (fps embedding, context tokens, image-latent
-    features), once per video, stock torch ops in fp32 on the device.  Shapes as the pipeline passes them:
+    """the sample- and timestep-independent part of I2VGenXLUNet.forward (fps embedding, context tokens, image-latent features: what
+    video_gen/pipeline_i2vgen_xl.py:604-639 prepares), once per video, on the library's fp32 kernels (csrc/conditioning.hip: layers of 4 .. 64
+    channels, nothing an MFMA tile could be filled with).  Shapes as the pipeline passes them:
     fps [B], image_latents [B,4,F,h,w], image_embeddings [B,cross], encoder_hidden_states [B,77,cross]."""
     cfg, dev = W.cfg, W.device
-    p = {k: v.to(dev, F32) for k, v in W.raw.items()}
-    lin = lambda x, n: F.linear(x, p[n + ".weight"], p[n + ".bias"])
+    p = {k: v.to(dev, F32).contiguous() for k, v in W.raw.items()}
+    lin = lambda x, n, **kw: ops.linear_f32(x, p[n + ".weight"], p[n + ".bias"], **kw)
+    conv = lambda x, n, **kw: ops.conv3x3_f32(x, p[n + ".weight"], p[n + ".bias"], **kw)
     B, Cc, Fr, H, Wd = image_latents.shape
     il = image_latents.to(dev, F32)
-    half = cfg.block_out_channels[0] // 2
-    freqs = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(half, dtype=F32) / half).to(dev)
-    a = fps.to(dev, F32)[:, None] * freqs[None]
-    fps_emb = lin(F.silu(lin(torch.cat([torch.cos(a), torch.sin(a)], -1), "fps_embedding.0")), "fps_embedding.2")
+    sin = torch.empty(B, cfg.block_out_channels[0], device=dev, dtype=F32)
+    L.check(L.load().tmix_timestep_embedding(fps.to(dev, F32).contiguous().data_ptr(), sin.data_ptr(), B, cfg.block_out_channels[0],
+                                             torch.cuda.current_stream().cuda_stream), "tmix_timestep_embedding")
+    fps_emb = lin(lin(sin, "fps_embedding.0", act_out=True), "fps_embedding.2")
     n = "image_latents_context_embedding"
-    v = F.silu(F.conv2d(il[:, :, 0], p[n + ".0.weight"], p[n + ".0.bias"], padding=1))
-    v = F.adaptive_avg_pool2d(v, (cfg.ctx_pool, cfg.ctx_pool))
-    v = F.silu(F.conv2d(v, p[n + ".3.weight"], p[n + ".3.bias"], stride=2, padding=1))
-    v = F.conv2d(v, p[n + ".5.weight"], p[n + ".5.bias"], stride=2, padding=1)
+    v = conv(il[:, :, 0].contiguous(), n + ".0", silu=True)
+    v = ops.adaptive_avgpool_f32(v, cfg.ctx_pool, cfg.ctx_pool)
+    v = conv(conv(v, n + ".3", stride=2, silu=True), n + ".5", stride=2)
     ctx_img = v.permute(0, 2, 3, 1).reshape(B, -1, cfg.cross_dim)
-    e = lin(F.silu(lin(image_embeddings.to(dev, F32), "context_embedding.0")), "context_embedding.2").view(B, cfg.in_channels, cfg.cross_dim)
+    e = lin(lin(image_embeddings.to(dev, F32).contiguous(), "context_embedding.0", act_out=True), "context_embedding.2").view(B, cfg.in_channels, cfg.cross_dim)
     context = torch.cat([encoder_hidden_states.to(dev, F32), ctx_img, e], dim=1)
     n = "image_latents_proj_in"
-    x = il.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, H, Wd)
-    x = F.silu(F.conv2d(x, p[n + ".0.weight"], p[n + ".0.bias"], padding=1))
-    x = F.silu(F.conv2d(x, p[n + ".2.weight"], p[n + ".2.bias"], padding=1))
-    x = F.conv2d(x, p[n + ".4.weight"], p[n + ".4.bias"], padding=1)
-    x = x.view(B, Fr, Cc, H, Wd).permute(0, 3, 4, 1, 2).reshape(B * H * Wd, Fr, Cc)
-    n = "image_latents_temporal_encoder"
-    h = F.layer_norm(x, (Cc,), p[n + ".norm1.weight"], p[n + ".norm1.bias"], 1e-5)
-    q = F.linear(h, p[n + ".attn1.to_q.weight"]).view(-1, Fr, 2, Cc).transpose(1, 2)
-    k = F.linear(h, p[n + ".attn1.to_k.weight"]).view(-1, Fr, 2, Cc).transpose(1, 2)
-    vv = F.linear(h, p[n + ".attn1.to_v.weight"]).view(-1, Fr, 2, Cc).transpose(1, 2)
-    o = F.scaled_dot_product_attention(q, k, vv).transpose(1, 2).reshape(-1, Fr, 2 * Cc)
-    x = x + lin(o, n + ".attn1.to_out.0")
-    x = x + lin(F.gelu(lin(x, n + ".ff.net.0.proj")), n + ".ff.net.2")
-    il_feat = x.view(B, H, Wd, Fr, Cc).permute(0, 4, 3, 1, 2).contiguous()
+    x = il.permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, H, Wd).contiguous()
+    x = conv(conv(conv(x, n + ".0", silu=True), n + ".2", silu=True), n + ".4")
+    il_feat = ops.i2v_temporal_encoder(x, B, Fr, p, "image_latents_temporal_encoder")
     return fps_emb, context, il_feat
 
 

@@ -103,6 +103,10 @@ SIGNATURES = {
     "tmix_timestep_embedding": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "tmix_linear_small": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "tmix_linear_small_sections": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "tmix_conv3x3_f32": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 7 + [vp]),
+    "tmix_adaptive_avgpool_f32": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tmix_linear_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "tmix_i2v_temporal_encoder": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64] + [vp] * 11 + [vp]),
 }
 
 _lib = None

@@ -472,6 +472,61 @@ def linear_small(x, w, bias=None, add=None, act_in=False, act_out=False, out=Non
     return out
 
 
+def _f32c(*ts):
+    for t in ts:
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), "fp32 contiguous tensors"
+
+
+def conv3x3_f32(x, w, bias=None, stride=1, silu=False):
+    """x [B,Cin,H,W] fp32 NCHW, w [Cout,Cin,3,3] fp32 (checkpoint layout), padding 1 -> [B,Cout,OH,OW] fp32 (tmix_conv3x3_f32)."""
+    _need_cuda(x, w)
+    _f32c(x, w, bias)
+    B, Ci, H, W_ = x.shape
+    Co = w.shape[0]
+    assert tuple(w.shape) == (Co, Ci, 3, 3)
+    y = torch.empty(B, Co, (H - 1) // stride + 1, (W_ - 1) // stride + 1, device=x.device, dtype=torch.float32)
+    L.check(L.load().tmix_conv3x3_f32(_p(x), _p(w), _p(bias), _p(y), B, Ci, H, W_, Co, int(stride), int(bool(silu)), _stream()), "tmix_conv3x3_f32")
+    return y
+
+
+def adaptive_avgpool_f32(x, oh, ow):
+    """torch.nn.AdaptiveAvgPool2d((oh, ow)) on fp32 [..., H, W] (tmix_adaptive_avgpool_f32)."""
+    _need_cuda(x)
+    _f32c(x)
+    H, W_ = x.shape[-2:]
+    y = torch.empty(*x.shape[:-2], oh, ow, device=x.device, dtype=torch.float32)
+    L.check(L.load().tmix_adaptive_avgpool_f32(_p(x), _p(y), x.numel() // (H * W_), H, W_, int(oh), int(ow), _stream()), "tmix_adaptive_avgpool_f32")
+    return y
+
+
+def linear_f32(x, w, bias=None, act_in=False, act_out=False):
+    """x [M<=256,K] fp32, w [N,K] fp32 -> act_out(act_in(x) w^T + bias) [M,N] fp32 (tmix_linear_f32; act = SiLU)."""
+    _need_cuda(x, w)
+    _f32c(x, w, bias)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    L.check(L.load().tmix_linear_f32(_p(x), _p(w), _p(bias), _p(out), M, N, K, int(bool(act_in)), int(bool(act_out)), _stream()), "tmix_linear_f32")
+    return out
+
+
+def i2v_temporal_encoder(x, clips, frames, p, name):
+    """x [clips*frames, 4, H, W] fp32 -> [clips, 4, frames, H, W] fp32: the whole image_latents_temporal_encoder block (tmix_i2v_temporal_encoder);
+    p: fp32 state-dict entries under `name` (norm1, attn1.to_q/k/v, attn1.to_out.0, ff.net.0.proj, ff.net.2)."""
+    _need_cuda(x)
+    BF, Cc, H, W_ = x.shape
+    assert BF == clips * frames
+    ws = [p[name + k] for k in (".norm1.weight", ".norm1.bias", ".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_v.weight", ".attn1.to_out.0.weight",
+                                ".attn1.to_out.0.bias", ".ff.net.0.proj.weight", ".ff.net.0.proj.bias", ".ff.net.2.weight", ".ff.net.2.bias")]
+    _f32c(x, *ws)
+    want = [(Cc,), (Cc,), (2 * Cc, Cc), (2 * Cc, Cc), (2 * Cc, Cc), (Cc, 2 * Cc), (Cc,), (4 * Cc, Cc), (4 * Cc,), (Cc, 4 * Cc), (Cc,)]
+    assert [tuple(w.shape) for w in ws] == want, [tuple(w.shape) for w in ws]
+    y = torch.empty(clips, Cc, frames, H, W_, device=x.device, dtype=torch.float32)
+    L.check(L.load().tmix_i2v_temporal_encoder(_p(x), _p(y), clips, frames, Cc, H * W_, *[_p(w) for w in ws], _stream()), "tmix_i2v_temporal_encoder")
+    return y
+
+
 def softmax_rows_causal(scores, probs, seq, scale):
     """probs[r, :] = softmax(scale * scores[r, :c<=r%seq]) (bf16), zeros elsewhere; scores fp32 [rows, cols]."""
     _need_cuda(scores, probs)
