@@ -155,6 +155,11 @@ typedef struct {
      * layout under every tiling; tmix_groupnorm_nhwc_pre consumes it.  Plain bf16 epilogue only (no transposed region, no
      * activation, no row_stats_out / e4m3 copy), batch == 1, M %% 32 == 0, N %% 8 == 0, 16-byte aligned C / residual rows. */
     float* col_stats_out;
+    /* --- periodic weight sets (several independent seeds share every UNet launch: batch rows [seed][concept], and row b of the batch wants the
+     * weights of concept b %% w_period): 0 = W / bias / ln_colsum (and the fp8 W scales) are indexed by the batch slice as their strides say;
+     * P > 0 (batch %% P == 0) = slice b reads set b %% P of P stored sets -- no gathered per-row copies of the merged LoRA weights
+     * (utils_lora.py:65-79,113-119 applied per row), and the slices that share a set are issued back to back. */
+    int32_t w_period, reserved1;
 } tmix_gemm_desc;
 int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
 /* Hint for the NEXT tmix_gemm_bf16 / tmix_conv3x3_nhwc launch issued by this host thread (consumed and cleared by it): while its

@@ -37,7 +37,7 @@ def test_descriptor_layouts():
     assert lib.GemmDesc.M.offset == 156 and lib.GemmDesc.epilogue.offset == 172 and lib.GemmDesc.tile_cfg.offset == 176
     assert lib.GemmDesc.row_stats_out.offset == 184 and lib.GemmDesc.ln_stats.offset == 208 and lib.GemmDesc.ln_colsum.offset == 232
     assert lib.GemmDesc.ln_inv_c.offset == 248 and lib.GemmDesc.ln_parts.offset == 256
-    assert lib.GemmDesc.col_stats_out.offset == 264 and ctypes.sizeof(lib.GemmDesc) == 272
+    assert lib.GemmDesc.col_stats_out.offset == 264 and lib.GemmDesc.w_period.offset == 272 and ctypes.sizeof(lib.GemmDesc) == 280
     assert lib.ConvDesc.B.offset == 48 and lib.ConvDesc.tile_cfg.offset == 72 and lib.ConvDesc.col_stats_out.offset == 80
     assert lib.ConvDesc.S1.offset == 88 and lib.ConvDesc.S2.offset == 96 and lib.ConvDesc.S2_channels.offset == 108 and ctypes.sizeof(lib.ConvDesc) == 112
 

@@ -1059,3 +1059,61 @@ def test_lora_down_fills_the_pad_columns(ops, P, ln):
     mask = ref == 0
     assert (a[:, K:].float()[mask] == 0).all()
 
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 4, 7, 12, 13, 14, 16, 17, 19, 20, 21])
+def test_gemm_periodic_weight_sets_equal_the_gathered_form(ops, cfg):
+    """tmix_gemm_desc.w_period: a batch of seeds x (1 + K) rows against 1 + K stored weight sets (slice b reads set b % P) is the same launch,
+    bit for bit, as the one over per-row gathered copies of the weights -- plain, with per-set bias + residual, with the folded LayerNorm
+    (per-set ln_colsum), and with a transposed V region."""
+    from tweediemix_amd.weights import fold_layernorm
+    P, seeds, M, K, N = 4, 3, 200, 256, 640
+    Bz = P * seeds
+    a = rnd(Bz, M, K, seed=301)
+    w = rnd(P, N, K, seed=302, scale=K ** -0.5)
+    bias = rnd(P, N, seed=303, dtype=torch.float32)
+    res = rnd(Bz, M, N, seed=304)
+    idx = torch.arange(Bz, device="cuda") % P
+    wg, bg = w[idx].contiguous(), bias[idx].contiguous()
+    kw = dict(tile_cfg=cfg) if cfg else {}
+    assert torch.equal(ops.gemm(a, w, **kw), ops.gemm(a, wg, **kw))
+    got = ops.gemm(a, w, bias=bias, residual=res, **kw)
+    assert torch.equal(got, ops.gemm(a, wg, bias=bg, residual=res, **kw))
+    close(got, torch.einsum("bmk,bnk->bmn", a.float(), wg.float()) + bg[:, None] + res.float())
+    # consumer of a folded LayerNorm: per-set colsum / bias
+    gamma, beta = rnd(K, seed=305, dtype=torch.float32) * 0.2 + 1, rnd(K, seed=306, dtype=torch.float32) * 0.3
+    fold = [fold_layernorm(w[i], gamma, beta, bias[i]) for i in range(P)]
+    wp, cs, t = [torch.stack([f[j] for f in fold]).contiguous() for j in range(3)]
+    h = (rnd(Bz, M, K, seed=307) * 2 + 0.5)
+    hf = h.float()
+    stats = torch.stack([hf.sum(-1), (hf ** 2).sum(-1)], -1).view(1, Bz * M, 2).contiguous()
+    y = ops.gemm(h, wp, bias=t, ln_stats=stats, ln_colsum=cs, **kw)
+    assert torch.equal(y, ops.gemm(h, wp[idx].contiguous(), bias=t[idx].contiguous(), ln_stats=stats, ln_colsum=cs[idx].contiguous(), **kw))
+    close(y, torch.einsum("bmk,bnk->bmn", F.layer_norm(hf, (K,), gamma, beta, 1e-5), wg.float()) + bg[:, None], rtol=2 ** -6, atol_frac=4e-3)
+    if cfg != 22:
+        w3 = rnd(P, 3 * 128, K, seed=308, scale=K ** -0.5)
+        vt1, vt2 = [torch.zeros(Bz, 128, 208, device="cuda", dtype=BF) for _ in range(2)]
+        q1 = ops.gemm(a, w3, out_t=vt1, n_trans_begin=256, **kw)
+        q2 = ops.gemm(a, w3[idx].contiguous(), out_t=vt2, n_trans_begin=256, **kw)
+        assert torch.equal(q1, q2) and torch.equal(vt1, vt2)
+
+
+@pytest.mark.parametrize("tile", [0, 12, 16, 17, 21])
+def test_gemm_fp8_periodic_weight_sets_equal_the_gathered_form(ops, tile):
+    P, seeds, M, K, N = 4, 2, 256, 256, 640
+    Bz = P * seeds
+    a8, sa = ops.quantize_fp8_rows(rnd(Bz, M, K, seed=311))
+    w8, sw = ops.quantize_fp8_rows(rnd(P, N, K, seed=312, scale=K ** -0.5))
+    idx = torch.arange(Bz, device="cuda") % P
+    kw = dict(tile_cfg=tile) if tile else {}
+    got = ops.gemm_fp8(a8, sa, w8, sw, **kw)
+    assert torch.equal(got, ops.gemm_fp8(a8, sa, w8[idx].contiguous(), sw[idx].contiguous(), **kw))
+
+
+def test_gemm_rejects_a_period_that_does_not_divide_the_batch(ops):
+    import ctypes as C
+    from tweediemix_amd import lib as L
+    a, w = rnd(6, 64, 64, seed=1), rnd(4, 64, 64, seed=2)
+    d = ops.make_gemm_desc(a[:4], w, torch.empty(4, 64, 64, device="cuda", dtype=BF))
+    d.batch, d.w_period = 6, 4
+    assert L.load().tmix_gemm_bf16(C.byref(d), None) == L.ESHAPE

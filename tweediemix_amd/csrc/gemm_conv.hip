@@ -123,8 +123,12 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     if ((d->epilogue == TMIX_EPI_GELU || d->epilogue == TMIX_EPI_QUICKGELU) && (has_trans || d->residual)) TMIX_FAIL(TMIX_EINVAL, "gemm: activation epilogues take no residual/transposed region");
     if (d->epilogue == TMIX_EPI_F32OUT && (has_trans || (((uintptr_t)d->C) & 15))) TMIX_FAIL(TMIX_EINVAL, "gemm: fp32 output needs a 16-byte aligned C and no transposed region");
     if ((int64_t)d->M * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldw >= (1ll << 31)) TMIX_FAIL(TMIX_ESHAPE, "gemm: operand extent exceeds 32-bit element offsets");
+    if (d->w_period < 0 || (d->w_period > 0 && (d->batch % d->w_period))) TMIX_FAIL(TMIX_ESHAPE, "gemm: w_period=%d must divide batch=%d", d->w_period, d->batch);
     Params p = {};
     p.A = (const bf16_t*)d->A; p.lda = d->lda; p.strideA = d->strideA;
+    p.w_period = d->w_period > 0 ? d->w_period : 0; p.w_groups = d->w_period > 0 ? d->batch / d->w_period : 1;
+    p.w_magic = (unsigned)((1ull << 32) / (unsigned)p.w_groups) + 1u;
+    if (d->batch > 65535) TMIX_FAIL(TMIX_ESHAPE, "gemm: batch=%d exceeds the grid's 65535 slices", d->batch);
     p.W = (const bf16_t*)d->W; p.ldw = d->ldw; p.strideW = d->strideW;
     p.C = (bf16_t*)d->C; p.ldc = d->ldc; p.strideC = d->strideC;
     p.bias = d->bias; p.strideBias = d->strideBias;

@@ -90,6 +90,7 @@ struct Params {
     unsigned char* f8copy; int64_t ldF8copy;                    // plain epilogue: e4m3 COPY of the stored bf16 rows (+ scale_out [N/32][ldScaleOut])
     const char* pf; long long pf_bytes;                         // tmix_gemm_prefetch_next: the next launch's weights, touched in the prologue
     int pf_per;                                                 // 128-byte lines per touching thread (host-computed: a 64-bit division in every wave's prologue otherwise)
+    int w_period, w_groups; unsigned w_magic;                   // > 0: batch slice b takes weight set (bias, ln_colsum, fp8 W scales) b % w_period; w_groups = batch / w_period, w_magic = floor(2^32 / w_groups) + 1
     float* cs_out;                                              // GroupNorm producer side: fp32 [M/32][2][N] column {sums | sums of squares} per 32-row block
     // convolution with 1x1 SHORTCUT taps (SC): behind the nine 3x3 taps the K loop walks the channels of up to two more NHWC tensors at the output pixel
     const bf16_t* S1; const bf16_t* S2; int c1s, c2s; unsigned bytesS1, bytesS2;
@@ -233,10 +234,14 @@ gemm_conv_kernel(const Params p) {
     const int tile_n = rem / gsize, tile_m = first_m + (rem - tile_n * gsize);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int m0l = (ABL & 1) ? 0 : m0, n0l = (ABL & 1) ? 0 : n0;      // rows the STAGING reads (ablation bit 0: tile (0, 0))
-    const int bz = blockIdx.y;
+    // periodic weight sets (co-batched seeds: rows [seed][concept] share the concept's weights): slices that read the same W are issued back to back
+    // (by / w_groups as a multiply-high by the host's reciprocal: scalar instructions only, exact for by, w_groups < 65536)
+    const int by = blockIdx.y;
+    const int bzw = p.w_period > 0 ? (int)__umulhi((unsigned)by, p.w_magic) : by;       // == bz % w_period
+    const int bz = p.w_period > 0 ? (by - bzw * p.w_groups) * p.w_period + bzw : by;
 
     const bf16_t* Ab = (const bf16_t*)((const char*)p.A + (int64_t)bz * p.strideA * EB);      // strides count elements (fp8: bytes)
-    const bf16_t* Wb = (const bf16_t*)((const char*)p.W + (int64_t)bz * p.strideW * EB);
+    const bf16_t* Wb = (const bf16_t*)((const char*)p.W + (int64_t)bzw * p.strideW * EB);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, p.bytesW, 0x00020000);
 
@@ -484,7 +489,7 @@ gemm_conv_kernel(const Params p) {
     // registers across the last K-tiles pushed the 128 x 160 tilings past 256 VGPRs
     float* bias_lds = ln_rs + BM;
     float bias_r = 0.f;
-    if (p.bias && tid < BN && n0 + tid < p.N) bias_r = (p.bias + (int64_t)bz * p.strideBias)[n0 + tid];
+    if (p.bias && tid < BN && n0 + tid < p.N) bias_r = (p.bias + (int64_t)bzw * p.strideBias)[n0 + tid];
     // convolution: the time-embedding row of the tile's image likewise (every tile of this path lies inside one image; a tile that
     // straddles two row groups takes the generic epilogue, which looks the row up per output row)
     float* rgb_lds = bias_lds + BN;
@@ -512,7 +517,7 @@ gemm_conv_kernel(const Params p) {
             for (int q = 0; q < PU; ++q)
                 if (q < p.ln_parts) lnv[q] = __builtin_amdgcn_raw_buffer_load_b64(rsS, lnm * 8, q * (int)p.ldLnStats * 8, 0);
         }
-        if (tid < BN) ln_cs = (p.ln_colsum + (int64_t)bz * p.strideLnColsum)[min(n0 + tid, p.N - 1)];
+        if (tid < BN) ln_cs = (p.ln_colsum + (int64_t)bzw * p.strideLnColsum)[min(n0 + tid, p.N - 1)];
     }
     // x = x1 + x2 + x3 (bf16 pieces by truncation, exact residuals): operand halves {x1,x1,x2,0 | x1,x3,x2,0} for -mean
     // and {x1,x2,x1,0 | x3,x1,x2,0} for colsum pair up to the six products x_a * y_b with a + b <= 4 (~24 bits)
@@ -630,7 +635,7 @@ gemm_conv_kernel(const Params p) {
         int f8sA[F8 ? FM : 1], f8sW[F8 ? FN : 1];      // fp8: this lane's row scales, the E8M0 byte replicated into all four byte lanes
         if constexpr (F8) {
             const unsigned char* sa = p.scaleA + (int64_t)bz * p.strideScaleA;
-            const unsigned char* sw = p.scaleW + (int64_t)bz * p.strideScaleW;
+            const unsigned char* sw = p.scaleW + (int64_t)bzw * p.strideScaleW;
 #pragma unroll
             for (int i = 0; i < FM; ++i) f8sA[i] = F8B ? 0 : (int)(sa[min(m0 + wr * TM + i * 32 + l31, p.M - 1)] * 0x01010101u);
 #pragma unroll
@@ -783,7 +788,7 @@ gemm_conv_kernel(const Params p) {
     int f8a[2][(F8L && F8B) ? FM : 1];                 // MX-block scale of the A fragment (E8M0 byte in all four byte lanes), double-buffered with it
     int f8sA[(F8L && !F8B) ? FM : 1], f8sW[F8L ? FN : 1];
     if constexpr (F8L) {
-        const unsigned char* swp_ = p.scaleW + (int64_t)bz * p.strideScaleW;
+        const unsigned char* swp_ = p.scaleW + (int64_t)bzw * p.strideScaleW;
 #pragma unroll
         for (int j = 0; j < FN; ++j) f8sW[j] = (int)(swp_[min(n0 + wc * TN + j * 32 + l31, p.N - 1)] * 0x01010101u);
         if constexpr (!F8B) {
@@ -965,7 +970,7 @@ gemm_conv_kernel(const Params p) {
     }
 
     // 32x32 accumulator: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const float* bias = p.bias ? p.bias + (int64_t)bz * p.strideBias : nullptr;
+    const float* bias = p.bias ? p.bias + (int64_t)bzw * p.strideBias : nullptr;
     // ---- LDS-staged ("wide") stores.  In the accumulator layout a lane owns 4 consecutive outputs of ONE row, so a store
     // instruction scatters 64 x 8 bytes over 32 rows: 32 partial-line requests per instruction, and the epilogue of a
     // 256 x 256 tile took 14-24 us (a quarter to a half of the whole workgroup; tools/gemm_lab `tl`).  The staging ring is

@@ -45,7 +45,7 @@ class GemmDesc(C.Structure):
                 ("ln_stats", vp), ("strideLnStats", i64), ("ldLnStats", i64),
                 ("ln_colsum", vp), ("strideLnColsum", i64), ("ln_inv_c", f32), ("ln_eps", f32),
                 ("ln_parts", C.c_int32), ("reserved0", C.c_int32),
-                ("col_stats_out", vp)]
+                ("col_stats_out", vp), ("w_period", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class ConvDesc(C.Structure):

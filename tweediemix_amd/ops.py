@@ -80,7 +80,9 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
     d = L.GemmDesc()
     d.A, d.lda, d.strideA = a3.data_ptr(), a3.stride(1), (a3.stride(0) if batch > 1 else 0)
     d.W, d.ldw, d.strideW = w3.data_ptr(), w3.stride(1), (w3.stride(0) if w3.shape[0] > 1 else 0)
-    assert w3.shape[0] in (1, batch)
+    P = w3.shape[0]
+    assert P in (1, batch) or batch % P == 0          # P weight sets for a batch of several x P rows: slice b reads set b % P (tmix_gemm_desc.w_period)
+    d.w_period = P if 1 < P < batch else 0
     if out is not None:
         o3 = out if out.dim() == 3 else out.unsqueeze(0)
         assert o3.dtype == BF16 and o3.stride(2) == 1
@@ -89,6 +91,7 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
         assert bias.dtype == torch.float32 and bias.stride(-1) == 1
         d.bias = bias.data_ptr()
         d.strideBias = bias.stride(0) if (bias.dim() == 2 and bias.shape[0] > 1) else 0
+        assert bias.dim() == 1 or bias.shape[0] in (1, P)
     if residual is not None:
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
         assert r3.dtype == BF16 and r3.stride(2) == 1
@@ -118,7 +121,7 @@ def make_gemm_desc(a, w, out, bias=None, residual=None, rowgroup_bias=None, rows
         st = ln_stats
         assert st.dtype == torch.float32 and st.is_contiguous() and st.dim() == 3 and st.shape[1:] == (batch * M, 2)
         assert ln_colsum is not None and ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous()
-        assert ln_colsum.shape in ((N,), (batch, N))
+        assert ln_colsum.shape in ((N,), (P, N))
         d.ln_stats, d.strideLnStats, d.ldLnStats = st.data_ptr(), 2 * M, st.shape[1]
         d.ln_parts = int(ln_parts) if ln_parts else st.shape[0]
         d.ln_colsum, d.strideLnColsum = ln_colsum.data_ptr(), (N if ln_colsum.dim() == 2 and batch > 1 else 0)

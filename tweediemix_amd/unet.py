@@ -644,7 +644,12 @@ class UNetPlan:
         # the N = 1280 / 640 launches (attention out-projections, attn2 to_q, FF2): 128 x 160 tiles fill the chip where 256 x 128 leaves 96 CUs idle, and
         # on e4m3 operands the lock-step loop with loader waves runs FF2 at 1.7 PFLOP/s (31 us against 45.5 for the phase-offset 256 x 128, 51.5 in bf16)
         Ng, Kg = w8.shape[-2], w8.shape[-1]
-        if self.fp8_tile and f8_out is None and kw.get("out_t") is None and Kg % 128 == 0 and Ng % 160 == 0 and Ng <= 1280:
+        # ... where the launch is one round of them or K is long; with more rows (co-batched seeds: B = 8 / 16, the 64 x 64 level) the phase-offset 256 x 256
+        # tiling wins the K <= 1280 launches again (tools/cobatch_tiles.py: B = 16 cube 50.8 vs 55.3 us, 640-cube 55.7 vs 69.0; B = 4 cube 22.3 vs 16.9)
+        rows_g = a8.shape[-2] * (a8.shape[0] if a8.dim() == 3 else 1)
+        lock = self.fp8_tile and f8_out is None and kw.get("out_t") is None and Kg % 128 == 0 and Ng % 160 == 0 and Ng <= 1280
+        many = not (Kg >= 2560 or rows_g * Ng <= 4096 * 1280)
+        if lock and (not many or kw.get("row_stats_out") is not None):       # (with the row statistics + e4m3 copy epilogue the 128 x 160 tiles stay ahead: 64 vs 72.5 us at B = 16)
             kw.setdefault("tile_cfg", self.fp8_tile)
         if kw.get("row_stats_out") is not None:
             kw.setdefault("tile_cfg", 17)           # explicit (the partial count depends on it)
@@ -843,14 +848,19 @@ class UNetPlan:
             kw["residual"] = kw["residual"].view(*shp, kw["residual"].shape[-1])
         w = self._rows(key) if self.routed else W[key]
         if fp8 and self.fp8:
-            kw["fp8_key"] = (key + "_rows", tuple(self.row_sets)) if self.routed else key
+            kw["fp8_key"] = (key + "_rows", tuple(range(w.shape[0])) if self._periodic(w.shape[0]) else tuple(self.row_sets)) if self.routed else key
             kw["a8"] = a8
         return self._gemm(a.view(*shp, Cin), w, out.view(*shp, out.shape[-1]), **kw)
+
+    def _periodic(self, P):
+        """are the batch rows' weight sets 0 .. P-1 repeated (co-batched seeds, each with its 1 + K prompt rows in order)?"""
+        rs = list(self.row_sets)
+        return len(rs) % P == 0 and rs == list(range(P)) * (len(rs) // P)
 
     def _rows(self, key, suffix=""):
         """[B, N, K] per-row weight sets for a routed projection (a view when rows are 0..K in order)."""
         w = self.W[key + "_rows" + suffix]
-        if self.row_sets == list(range(w.shape[0])):
+        if self._periodic(w.shape[0]):                # several seeds x (1 + K) rows: the GEMM reads set b % (1 + K) (tmix_gemm_desc.w_period), no gathered copies
             return w
         if key + suffix not in self._rows_cache:
             self._rows_cache[key + suffix] = w[torch.tensor(self.row_sets, device=w.device)].contiguous()
