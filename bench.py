@@ -174,11 +174,12 @@ def insitu_profile(tw, reps=3, kind="fusion", mode=None):
     plan = tw.plan(kind)
     meta = plan.issued_meta()
     n = len(meta)
-    slots = torch.zeros(n, 8, dtype=torch.int64, device=tw.device)
-    init = torch.zeros(n, 8, dtype=torch.int64)
+    cap = n + 64                                        # spare slots: a launch the plan's meta list does not know would shift every later stamp -- caught below
+    slots = torch.zeros(cap, 8, dtype=torch.int64, device=tw.device)
+    init = torch.zeros(cap, 8, dtype=torch.int64)
     init[:, 0] = -1                                     # UINT64_MAX
     init = init.to(tw.device)
-    L.check(lib.tmix_prof_begin(slots.data_ptr(), n, 0), "tmix_prof_begin")
+    L.check(lib.tmix_prof_begin(slots.data_ptr(), cap, 0), "tmix_prof_begin")
     try:
         if tw.use_graphs:
             g = torch.cuda.CUDAGraph()
@@ -191,9 +192,9 @@ def insitu_profile(tw, reps=3, kind="fusion", mode=None):
         used = lib.tmix_prof_end()
     if run is None:                                     # eager mode: instrument every run
         def run():
-            lib.tmix_prof_begin(slots.data_ptr(), n, 0)
+            lib.tmix_prof_begin(slots.data_ptr(), cap, 0)
             tw._enqueue_step(kind, mode)
-            lib.tmix_prof_end()
+            assert lib.tmix_prof_end() == n
     else:
         assert used == n, (used, n)
     plain_ms = None

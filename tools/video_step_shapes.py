@@ -15,9 +15,10 @@ plans = plan.plans[1:] + plan.plans[:1] if streams == 2 else [plan]
 meta = [m for p in plans for m in p.issued_meta()]
 n = len(meta)
 plan.run(); torch.cuda.synchronize()
-slots = torch.zeros(n, 8, dtype=torch.int64, device="cuda")
-init = torch.zeros(n, 8, dtype=torch.int64); init[:, 0] = -1; init = init.cuda()
-L.check(lib.tmix_prof_begin(slots.data_ptr(), n, 0), "prof")
+cap = n + 4096                                   # spare slots, so that a launch without a meta entry shows up as used != n
+slots = torch.zeros(cap, 8, dtype=torch.int64, device="cuda")
+init = torch.zeros(cap, 8, dtype=torch.int64); init[:, 0] = -1; init = init.cuda()
+L.check(lib.tmix_prof_begin(slots.data_ptr(), cap, 0), "prof")
 gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr):
     plan.run()

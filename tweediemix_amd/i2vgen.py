@@ -263,6 +263,7 @@ class I2VPlan(UNetPlan):
         W = self.W
         self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
                    W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), Bn, HW, self.cfg.norm_groups, eps, int(silu))
+        self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", Bn, HW, Cc))      # (every instrumented launch needs its entry: the slots are dealt out in issue order)
         return out
 
     def _inject_site(self, buf, site, per_frame):
@@ -281,6 +282,7 @@ class I2VPlan(UNetPlan):
         self.flops += fl
         self.launches["conv"].append((d, fl))
         self._tunable.append((len(self.ops) - 1, "conv", d))
+        self.op_meta[len(self.ops) - 1] = ("conv", fl, d)
         return out
 
     def _temp_conv(self, x, Cc, HW, name):
