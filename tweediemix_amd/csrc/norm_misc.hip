@@ -812,72 +812,69 @@ extern "C" int tmix_lora_down(void* A, int64_t lda, int K, int64_t rows, const v
 }
 
 // ------------------------------------------------------------------------------ temporal attention (frame axis, S <= 16)
-// I2VGen-XL's TransformerTemporalModel attends over the FRAMES of one pixel: sequences of 16 tokens, head size 64, one
-// (clip, pixel, head) item per wave.  Lane = (query frame i = lane & 15, 16-wide slice c = lane >> 4 of the head dimension).
+// I2VGen-XL's TransformerTemporalModel attends over the FRAMES of one pixel: sequences of 16 tokens, head size 64, one (clip, pixel, head) item per wave,
+// on the matrix cores: S^T = K Q^T is two v_mfma_f32_16x16x32_bf16 (operands straight from global memory: a lane's fragment is 16 contiguous bytes of
+// its frame's row), the softmax runs over the four scores a lane holds and its three partner lanes (xor 16 / 32), and the exponentials ARE the B operand of
+// O^T = V^T P^T (four v_mfma_f32_16x16x16_bf16, one per 16 channels) -- only V has to turn: its rows go through LDS and come back as four 2-byte reads per
+// MFMA.  The round-3 form did the 2 x 16 x 16 x 64 multiply-adds of an item on the VALU (~175 us for the 86,016 x 5 items of the first level against
+// ~100 us of HBM time for its 440 MB).
 namespace {
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 ta_frag;
+constexpr int TA_VLD = 68;                       // LDS row of V: 64 channels + 4 pad (136 B: the four frames a lane group reads sit 8 banks apart)
 __global__ void __launch_bounds__(256) temporal_attn_kernel(const bf16_t* __restrict__ QKV, int64_t ld, bf16_t* __restrict__ O, int64_t ldo,
                                                             int frames, int64_t hw, int heads, int64_t items, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) bf16_t sK[4][16][64], sV[4][16][64];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[4][16][TA_VLD];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + w;
     const bool live = item < items;
     const int C = heads * 64;
-    const int i = lane & 15, c = lane >> 4;
+    const int r = lane & 15, g = lane >> 4;
     const int64_t ph = live ? item : 0;
     const int h = (int)(ph % heads);
     const int64_t cp = ph / heads;                                   // clip * hw + pixel
     const int64_t clip = cp / hw, pix = cp - clip * hw;
-    const int64_t row = (clip * frames + (i < frames ? i : 0)) * hw + pix;      // token row of frame i
-    const bf16_t* q = QKV + row * ld + h * 64 + c * 16;
-    uint4 qa = *(const uint4*)q, qb = *(const uint4*)(q + 8);
-    *(uint4*)&sK[w][i][c * 16] = *(const uint4*)(q + C);
-    *(uint4*)&sK[w][i][c * 16 + 8] = *(const uint4*)(q + C + 8);
-    *(uint4*)&sV[w][i][c * 16] = *(const uint4*)(q + 2 * C);
-    *(uint4*)&sV[w][i][c * 16 + 8] = *(const uint4*)(q + 2 * C + 8);
-    __syncthreads();
-    float qf[16];
+    const int64_t row = (clip * frames + (r < frames ? r : 0)) * hw + pix;      // token row of frame r (padding frames re-read frame 0: finite values)
+    const bf16_t* q = QKV + row * ld + h * 64;
+    // fragments of the score MFMAs: lane (r, g) holds channels [32 kb + 8 g, +8) of frame r -- K as A (rows = key frames), Q as B (columns = query frames)
+    const ta_frag k0 = *(const ta_frag*)(q + C + g * 8), k1 = *(const ta_frag*)(q + C + 32 + g * 8);
+    const ta_frag q0 = *(const ta_frag*)(q + g * 8), q1 = *(const ta_frag*)(q + 32 + g * 8);
+    // V rows -> LDS (lane: frame r, channels [16 g, +16))
     {
-        const unsigned u[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-#pragma unroll
-        for (int d = 0; d < 8; ++d) { qf[2 * d] = bf2f((bf16_t)(u[d] & 0xffff)) * scale_log2e; qf[2 * d + 1] = bf2f((bf16_t)(u[d] >> 16)) * scale_log2e; }
+        const uint4 va = *(const uint4*)(q + 2 * C + g * 16), vb = *(const uint4*)(q + 2 * C + g * 16 + 8);
+        uint2* dst = (uint2*)&sV[w][r][g * 16];
+        dst[0] = make_uint2(va.x, va.y); dst[1] = make_uint2(va.z, va.w); dst[2] = make_uint2(vb.x, vb.y); dst[3] = make_uint2(vb.z, vb.w);
     }
-    float sc[16];
-    float mx = -INFINITY;
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, st, 0, 0, 0);          // st[j] = K[4 g + j] . Q[r]
+    float sc[4], mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float a = 0.f;
-        const uint4 ka = *(const uint4*)&sK[w][j][c * 16], kb = *(const uint4*)&sK[w][j][c * 16 + 8];
-        const unsigned u[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-#pragma unroll
-        for (int d = 0; d < 8; ++d) { a = fmaf(qf[2 * d], bf2f((bf16_t)(u[d] & 0xffff)), a); a = fmaf(qf[2 * d + 1], bf2f((bf16_t)(u[d] >> 16)), a); }
-        a += __shfl_xor(a, 16);
-        a += __shfl_xor(a, 32);
-        sc[j] = j < frames ? a : -INFINITY;
-        mx = fmaxf(mx, sc[j]);
-    }
+    for (int j = 0; j < 4; ++j) { sc[j] = (4 * g + j) < frames ? st[j] * scale_log2e : -INFINITY; mx = fmaxf(mx, sc[j]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { sc[j] = exp2f(sc[j] - mx); sum += sc[j]; }
+    for (int j = 0; j < 4; ++j) { sc[j] = exp2f(sc[j] - mx); sum += sc[j]; }          // 0 for padded frames
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    float o[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) o[d] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint4 va = *(const uint4*)&sV[w][j][c * 16], vb = *(const uint4*)&sV[w][j][c * 16 + 8];
-        const unsigned u[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const float pj = sc[j];                                       // 0 for padded frames
-#pragma unroll
-        for (int d = 0; d < 8; ++d) { o[2 * d] = fmaf(pj, bf2f((bf16_t)(u[d] & 0xffff)), o[2 * d]); o[2 * d + 1] = fmaf(pj, bf2f((bf16_t)(u[d] >> 16)), o[2 * d + 1]); }
+    short4_t pb;                                                                     // P^T as the B operand: column = query r, k = keys 4 g .. 4 g + 3
+    {
+        const unsigned lo = pack_bf2(sc[0], sc[1]), hi = pack_bf2(sc[2], sc[3]);
+        pb = (short4_t){(short)(lo & 0xffff), (short)(lo >> 16), (short)(hi & 0xffff), (short)(hi >> 16)};
     }
-    if (live && i < frames) {
-        uint4 a, b;
-        a.x = pack_bf2(o[0] * inv, o[1] * inv);   a.y = pack_bf2(o[2] * inv, o[3] * inv);
-        a.z = pack_bf2(o[4] * inv, o[5] * inv);   a.w = pack_bf2(o[6] * inv, o[7] * inv);
-        b.x = pack_bf2(o[8] * inv, o[9] * inv);   b.y = pack_bf2(o[10] * inv, o[11] * inv);
-        b.z = pack_bf2(o[12] * inv, o[13] * inv); b.w = pack_bf2(o[14] * inv, o[15] * inv);
-        bf16_t* dst = O + row * ldo + h * 64 + c * 16;
-        *(uint4*)dst = a; *(uint4*)(dst + 8) = b;
+    __syncthreads();
+    bf16_t* dst = O + row * ldo + h * 64 + 4 * g;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        // V^T as the A operand: row = channel 16 db + r, k = keys 4 g .. 4 g + 3
+        short4_t va;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = (short)sV[w][4 * g + j][16 * db + r];
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, o, 0, 0, 0);          // o[j] = O[query r][channel 16 db + 4 g + j] * sum
+        if (live && r < frames) *(uint2*)(dst + 16 * db) = make_uint2(pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv));
     }
 }
 }  // namespace
