@@ -121,6 +121,19 @@ class I2VWeights:
     def __getitem__(self, k):
         return self.t[k]
 
+    def stacked_time_proj(self):
+        """as UNetWeights.stacked_time_proj: every ResnetBlock2D's time_emb_proj stacked along N (weight [sum Co, T] bf16, bias fp32, section starts on the
+        device, names), built once -- one tmix_linear_small_sections launch per step instead of one tmix_linear_small per resnet"""
+        if getattr(self, "_tproj", None) is None:
+            names = sorted(k[:-len(".time_emb_proj.weight")] for k in self.t if k.endswith(".time_emb_proj.weight"))
+            w = torch.cat([self.t[n + ".time_emb_proj.weight"] for n in names], 0).contiguous()
+            b = torch.cat([self.t[n + ".time_emb_proj.bias"].float() for n in names], 0).contiguous()
+            st = [0]
+            for n in names:
+                st.append(st[-1] + self.t[n + ".time_emb_proj.weight"].shape[0])
+            self._tproj = (w, b, torch.tensor(st, device=w.device, dtype=torch.int32), names)
+        return self._tproj
+
     def conv2_with_shortcut(self, name):
         """as UNetWeights.conv2_with_shortcut: ([Co, 9*Co + Ci] rows [conv2 taps | conv_shortcut], the two biases' sum), built once"""
         k = name + ".conv2+shortcut"
@@ -250,12 +263,9 @@ class I2VPlan(UNetPlan):
     # ------------------------------------------------------------------ emitters the image UNet did not need
     def _time_bias(self, name, Co, emb):
         """ResnetBlock2D as in the image UNet (UNetPlan._resnet), except that the time embedding exists once per CLIP ([clips, T]): its
-        projection is added to every frame of the clip through the conv's batch_bias_images."""
-        W = self.W
-        temb = torch.empty(self.clips, Co, device=self.dev, dtype=F32)
-        self.keep.append(temb)
-        self._emit(self.lib.tmix_linear_small, emb.data_ptr(), W[name + ".time_emb_proj.weight"].data_ptr(),
-                   W[name + ".time_emb_proj.bias"].data_ptr(), None, temb.data_ptr(), self.clips, Co, self.cfg.time_embed_dim, 1, 0)
+        projection (this block's section of the one stacked launch in _build) is added to every frame of the clip through the conv's batch_bias_images."""
+        temb = self._temb[name]
+        assert temb.shape == (self.clips, Co)
         return temb, self.frames
 
     def _gn_b(self, x, Bn, Cc, HW, name, eps, silu):
@@ -347,6 +357,13 @@ class I2VPlan(UNetPlan):
                    W["time_embedding.linear_1.bias"].data_ptr(), None, thid.data_ptr(), nc, T, C0, 0, 1)
         self._emit(lib.tmix_linear_small, thid.data_ptr(), W["time_embedding.linear_2.weight"].data_ptr(),
                    W["time_embedding.linear_2.bias"].data_ptr(), self.fps_emb.data_ptr(), emb.data_ptr(), nc, T, T, 0, 0)
+        tw, tb_, starts, names = W.stacked_time_proj()        # every ResnetBlock2D's time_emb_proj(SiLU(emb)) in ONE launch
+        tall = torch.empty(nc * tw.shape[0], device=self.dev, dtype=F32)
+        self.keep.append(tall)
+        self._emit(lib.tmix_linear_small_sections, emb.data_ptr(), tw.data_ptr(), tb_.data_ptr(), tall.data_ptr(), nc, tw.shape[0], T, 1,
+                   starts.data_ptr(), len(names))
+        hs = starts.tolist()
+        self._temb = {n: tall[hs[i] * nc:hs[i + 1] * nc].view(nc, hs[i + 1] - hs[i]) for i, n in enumerate(names)}
         Hh, Ww = self.h, self.w
         x = A.get(B, Hh * Ww, C0)
         self._emit(lib.tmix_conv_in, self.x_in.data_ptr(), W["conv_in.weight"].data_ptr(), W["conv_in.bias"].data_ptr(),
