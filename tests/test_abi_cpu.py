@@ -125,3 +125,9 @@ def test_argument_errors_are_reported_before_any_launch():
     assert l.tmix_i2v_temporal_encoder(fake, fake, 1, 16, 8, 64, *([fake] * 11), None) == lib.ESHAPE and b"channels" in l.tmix_last_error_string()
     assert l.tmix_i2v_temporal_encoder(fake, fake, 1, 17, 4, 64, *([fake] * 11), None) == lib.ESHAPE and b"frames" in l.tmix_last_error_string()
     assert l.tmix_i2v_temporal_encoder(fake, fake, 1, 16, 4, 64, *([fake] * 10), None, None) == lib.EINVAL
+    # periodic weight sets: the period must divide the batch
+    d = lib.GemmDesc()
+    d.A, d.W, d.C = 0x1000, 0x2000, 0x3000
+    d.M, d.N, d.K, d.batch, d.lda, d.ldw, d.ldc, d.n_trans_begin = 64, 64, 64, 6, 64, 64, 64, -1
+    d.strideA, d.strideW, d.strideC, d.w_period = 64 * 64, 64 * 64, 64 * 64, 4
+    assert l.tmix_gemm_bf16(C.byref(d), None) == lib.ESHAPE and b"w_period" in l.tmix_last_error_string()
