@@ -231,8 +231,10 @@ class I2VPlan(UNetPlan):
         self.fp8_attn_out = False
         self.fp8_tile = 0
         self.fp8_conv, self.fp8_conv_tile = False, 0
-        self._gn_fused = False                           # GroupNorm statistics stay with the statistics kernel here: the temporal norms span 16 frames
-                                                         # (86,016 rows per clip, beyond ops.COLSTATS_MAX_HW) and the injection sites rewrite resnet outputs in place
+        # GroupNorm statistics from the producers' column partials (UNetPlan._colstats) where 32-row blocks fit the normalised image: the per-frame norms of the
+        # first two levels (5376 / 1344 pixels) and the clip-wide norms of TemporalConvLayer / TransformerTemporalModel up to CLIP_COLSTATS_MAX rows (16 frames x HW is
+        # always a multiple of 32); the first level's clip-wide norms (86,016 rows = 2688 partial blocks per channel) and the injection sites keep the statistics kernel
+        self._gn_fused = not os.environ.get("TMIX_GN_STATS_KERNEL")
         self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")      # conv_shortcut in conv2's launch, no concat launches (UNetPlan._resnet)
         self.lib, self.dev = L.load(), W.device
         dev = self.dev
@@ -268,24 +270,46 @@ class I2VPlan(UNetPlan):
         assert temb.shape == (self.clips, Co)
         return temb, self.frames
 
+    CLIP_COLSTATS_MAX = 32768        # rows of a clip-wide norm whose combine launch walks the producers' partials (672 blocks per channel at the second level)
+
+    def _colstats(self, owner, rows, HW, Cc):
+        """as UNetPlan._colstats, for two kinds of readers: per-frame norms (HW pixels per image) and clip-wide norms (frames x HW rows per image)"""
+        R = ops.COLSTATS_ROWS
+        chw = self.frames * HW
+        ok = (HW % R == 0 and HW <= ops.COLSTATS_MAX_HW) or (chw % R == 0 and chw <= self.CLIP_COLSTATS_MAX)
+        if not self._gn_fused or not ok or rows % R or Cc % 8:
+            return None
+        cs = self.arena.get(rows // R, 2, Cc, dtype=F32)
+        owner._cs = ((cs, Cc),)
+        return cs
+
     def _gn_b(self, x, Bn, Cc, HW, name, eps, silu):
+        """GroupNorm over whole clips (Bn = clips images of HW = frames x hw rows)"""
         out = self.arena.get(*x.shape)
         W = self.W
-        self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
-                   W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), Bn, HW, self.cfg.norm_groups, eps, int(silu))
+        parts = getattr(x, "_cs", None)
+        if parts and len(parts) == 1 and parts[0][1] == Cc and HW % ops.COLSTATS_ROWS == 0 and HW <= self.CLIP_COLSTATS_MAX:
+            self._emit(self.lib.tmix_groupnorm_nhwc_pre, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(), W[name + ".bias"].data_ptr(),
+                       self._gn_ws.data_ptr(), Bn, HW, self.cfg.norm_groups, eps, int(silu), parts[0][0].data_ptr(), Cc, None, 0)
+        else:
+            self._emit(self.lib.tmix_groupnorm_nhwc, x.data_ptr(), Cc, None, 0, out.data_ptr(), W[name + ".weight"].data_ptr(),
+                       W[name + ".bias"].data_ptr(), self._gn_ws.data_ptr(), Bn, HW, self.cfg.norm_groups, eps, int(silu))
         self.op_meta[len(self.ops) - 1] = ("norm", 0, ("norm", Bn, HW, Cc))      # (every instrumented launch needs its entry: the slots are dealt out in issue order)
         return out
 
     def _inject_site(self, buf, site, per_frame):
         if site in self.INJECT_SITES:
             self.ops.append((_Inject(self, buf, per_frame, self.INJECT_SITES[site]), ()))
+            for cs, _c in getattr(buf, "_cs", None) or ():      # the injection rewrites the tensor behind its producer: the partials no longer describe it
+                self.arena.put(cs)
+            buf._cs = None
 
     def _conv_t3(self, x, wname, HW, Cc, residual=None):
         """Conv3d (3,1,1) over the frame axis: x [(clips frames), hw, C] seen as [clips, frames, hw, C]."""
         out = self.arena.get(self.B, HW, Cc)
         shp = (self.clips, self.frames, HW, Cc)
         d = ops.make_conv_desc(x.view(*shp), self.W[wname + ".weight"], out.view(*shp), self.W[wname + ".bias"], None,
-                               None if residual is None else residual, L.CONV_T3)
+                               None if residual is None else residual, L.CONV_T3, col_stats_out=self._colstats(out, self.B * HW, HW, Cc))
         self.keep.append(d)
         self._emit(self.lib.tmix_conv3x3_nhwc, C.byref(d))
         fl = 2 * self.B * HW * Cc * 3 * Cc
@@ -338,7 +362,7 @@ class I2VPlan(UNetPlan):
         self._gemm(f, W[tb + ".ff.net.2.weight"], h.view(M, inner), bias=W[tb + ".ff.net.2.bias"], residual=h.view(M, inner))
         A.put(f)
         out = A.get(self.B, HW, Cc)
-        self._gemm(h.view(M, inner), W[name + ".proj_out.weight"], out.view(M, Cc), bias=W[name + ".proj_out.bias"], residual=x.view(M, Cc))
+        self._gemm(h.view(M, inner), W[name + ".proj_out.weight"], out.view(M, Cc), bias=W[name + ".proj_out.bias"], residual=x.view(M, Cc), cs_owner=out)
         A.put(h)
         return out
 

@@ -573,7 +573,7 @@ class UNetPlan:
         if x2 is not None:
             p2 = getattr(x2, "_cs", None)
             parts = (parts[0], p2[0]) if parts and p2 and len(parts) == 1 and len(p2) == 1 else None
-        if parts and sum(c for _t, c in parts) == Cc:
+        if parts and sum(c for _t, c in parts) == Cc and HW % ops.COLSTATS_ROWS == 0:     # (video plans keep partials whose 32-row blocks fit the CLIP but not the frame)
             (cs1, c1), (cs2, c2) = (parts[0], parts[1]) if len(parts) == 2 else (parts[0], (None, 0))
             if f8:
                 self._emit(self.lib.tmix_groupnorm_nhwc_pre_f8, x.data_ptr(), Cc - C2, x2.data_ptr() if C2 else None, C2, out[0].data_ptr(), out[1].data_ptr(),
