@@ -306,3 +306,30 @@ def test_conditioning_runs_on_the_library_only(monkeypatch):
         monkeypatch.setattr(F, name, boom)
     fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
     assert rel(fe, fe_o) < 1e-4 and rel(ctx, ctx_o) < 1e-4 and rel(ilf, ilf_o) < 1e-4
+
+
+def test_groupnorm_statistics_from_producers_match_the_statistics_kernel(monkeypatch):
+    """the video plan takes the GroupNorm statistics of the per-frame norms (HW % 32 == 0) and of the clip-wide norms (TemporalConvLayer, TransformerTemporalModel)
+    from the producers' column partials; TMIX_GN_STATS_KERNEL=1 plans the three-launch form everywhere.  Same network, same weights; the injection sites keep the statistics kernel."""
+    from oracle import i2vgen_oracle as IO
+    from tweediemix_amd import i2vgen as I
+    B, Fr, H, W, Lk = 2, 16, 16, 8, 13
+    sd, il, emb, ehs, fps, sample = _setup(IO.TINY, I.TINY, B, Fr, H, W, Lk)
+    Wt = I.I2VWeights(I.TINY, sd)
+    fe, ctx, ilf = I.conditioning(Wt, fps, il, emb, ehs)
+    fused = I.I2VPlan(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    monkeypatch.setenv("TMIX_GN_STATS_KERNEL", "1")
+    plain = I.I2VPlan(Wt, B, Fr, H, W, fe, ctx, ilf, autotune=False)
+    names = lambda p: [getattr(fn, "__name__", "") for fn, _a in p.ops]
+    nf, npl = names(fused), names(plain)
+    assert npl.count("tmix_groupnorm_nhwc_pre") == 0 and nf.count("tmix_groupnorm_nhwc_pre") > nf.count("tmix_groupnorm_nhwc") > 0
+    assert nf.count("tmix_groupnorm_nhwc_pre") + nf.count("tmix_groupnorm_nhwc") == npl.count("tmix_groupnorm_nhwc")
+    # two evaluation orders of this bf16 network sit 1.4e-2 - 1.6e-2 apart whatever the difference is (the same plan under two tilings: 1.6e-2), each 1.4e-2 from
+    # the fp32 oracle: the two GroupNorm forms must be no further apart than that, with and without the injection
+    for inject in (False, True):
+        fused.inject = plain.inject = inject
+        a, b = fused(sample, 981).clone(), plain(sample, 981).clone()
+        assert rel(a, b) < 2.5e-2, (inject, rel(a, b))
+    want = IO.forward(sd, IO.TINY, sample, 981, *IO.conditioning(sd, IO.TINY, fps, il, emb, ehs))
+    fused.inject = plain.inject = False
+    assert rel(fused(sample, 981), want) < 2e-2 and rel(plain(sample, 981), want) < 2e-2
