@@ -201,22 +201,20 @@ def insitu_profile(tw, reps=3, kind="fusion", mode=None):
     if tw.use_graphs and (kind, mode) in tw.graphs:      # the un-instrumented graph the timed region replays, same moment
         ts_ = []
         for _ in range(reps + 1):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            torch.cuda.synchronize()              # (host clock: timing events around replays of a graph captured over two streams corrupt the heap on ROCm 7.0, unet.refine_group)
+            t0_ = time.perf_counter()
             tw.graphs[(kind, mode)].replay()
-            e1.record()
             torch.cuda.synchronize()
-            ts_.append(e0.elapsed_time(e1))
+            ts_.append(1e3 * (time.perf_counter() - t0_))
         plain_ms = sorted(ts_[1:])[len(ts_[1:]) // 2]
     runs = []
     for _ in range(reps + 1):
         slots.copy_(init)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        run()
-        e1.record()
         torch.cuda.synchronize()
-        runs.append((e0.elapsed_time(e1), slots.cpu().numpy().astype("uint64")))
+        t0_ = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        runs.append((1e3 * (time.perf_counter() - t0_), slots.cpu().numpy().astype("uint64")))
     runs = sorted(runs[1:], key=lambda r: r[0])
     wall_ms, sl = runs[len(runs) // 2]
     tick = 1e-5                                         # ms per tick of the 100 MHz clock

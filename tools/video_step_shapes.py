@@ -1,6 +1,6 @@
 """per-shape table of one I2VGen-XL step (BASELINE config #5, 2 clips x 16 frames x 56 x 96) from in-situ device-clock stamps inside the captured graph:
 python tools/video_step_shapes.py [1|2]   (launch chains: one plan over both clips, or the two clips as two chains = bench.py's video leg)"""
-import os, sys, collections, torch
+import os, sys, time, collections, torch
 sys.path.insert(0, os.getcwd())
 from tweediemix_amd import i2vgen as I, lib as L
 from tweediemix_amd.weights import synthetic_i2vgen_state_dict
@@ -27,9 +27,9 @@ assert used == n, (used, n)
 runs = []
 for _ in range(6):
     slots.copy_(init)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
-    runs.append((e0.elapsed_time(e1), slots.cpu().numpy().astype("uint64")))
+    torch.cuda.synchronize(); t0 = time.perf_counter()          # (host clock: see unet.refine_group on timing events and two-stream graphs)
+    gr.replay(); torch.cuda.synchronize()
+    runs.append((1e3 * (time.perf_counter() - t0), slots.cpu().numpy().astype("uint64")))
 runs = sorted(runs[1:], key=lambda r: r[0])
 ms, sl = runs[len(runs) // 2]
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])

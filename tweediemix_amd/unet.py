@@ -1116,14 +1116,17 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
             self.run()
         for _ in range(2):
             g.replay()
+        # host clock around a device-wide synchronize, not HIP events: timing events recorded around replays of a graph captured over TWO streams (the video
+        # step's two 978-launch chains) corrupt the process heap within a few dozen replays on ROCm 7.0 ("corrupted size vs. prev_size in fastbins" /
+        # "double free or corruption"; every run of tools/jobs4/r4zv_refine_video.sh), the same loop without them ran 400 re-captures clean
+        import time as _time
         ts = []
         for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            torch.cuda.synchronize()
+            t0 = _time.perf_counter()
             g.replay()
-            e1.record()
-            e1.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            torch.cuda.synchronize()
+            ts.append(1e3 * (_time.perf_counter() - t0))
         return sorted(ts)[len(ts) // 2]
 
     plans = _plans_of(self)
@@ -1145,6 +1148,8 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
                 d.tile_cfg = cfg
             for p in plans:
                 p._link_ln()
+            if os.environ.get("TMIX_REFINE_TRACE"):
+                print(f"    try {k} cfg {cfg}", flush=True)
             t = timed()
             if t < best_t - 0.02:                       # 20 us: above the replay-to-replay noise of the median
                 best, best_t = cfg, t
