@@ -29,3 +29,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def sdxl_weights():
+    """the real SDXL-base parameter shapes (2.57 B), synthetic values, fp32 on the device, built once for the headline-size tests."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tweediemix_amd import unet as U, weights as Wt
+    return Wt.synthetic_state_dict(U.SDXL, seed=1234, device="cuda", dtype=torch.float32)

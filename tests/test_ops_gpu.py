@@ -1117,3 +1117,25 @@ def test_gemm_rejects_a_period_that_does_not_divide_the_batch(ops):
     d = ops.make_gemm_desc(a[:4], w, torch.empty(4, 64, 64, device="cuda", dtype=BF))
     d.batch, d.w_period = 6, 4
     assert L.load().tmix_gemm_bf16(C.byref(d), None) == L.ESHAPE
+
+
+@pytest.mark.parametrize("period", ["batch", 1])
+def test_gemm_period_equal_to_the_batch_is_the_plain_strided_walk(ops, period):
+    """tmix.h documents every w_period > 0 that divides the batch as valid.  P == batch ("every slice its own set") made w_groups = 1 and wrapped the
+    magic divisor to 1: slices >= 1 indexed A / C far outside the batch.  It is the plain strideW walk; P == 1 is one shared set."""
+    import ctypes as C
+    from tweediemix_amd import lib as L
+    Bz, M, K, N = 4, 128, 128, 256
+    a, w = rnd(Bz, M, K, seed=321), rnd(Bz, N, K, seed=322, scale=K ** -0.5)
+    want = ops.gemm(a, w)
+    guard = torch.full((Bz + 2, M, N), 7.0, device="cuda", dtype=BF)       # a slice in front of and behind the output: must stay untouched
+    out = guard[1:1 + Bz]
+    d = ops.make_gemm_desc(a, w, out)
+    P = Bz if period == "batch" else 1
+    d.w_period = P
+    if P == 1:
+        want = ops.gemm(a, w[:1].expand(Bz, N, K).contiguous())
+    L.check(L.load().tmix_gemm_bf16(C.byref(d), torch.cuda.current_stream().cuda_stream), "tmix_gemm_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert (guard[0] == 7).all() and (guard[-1] == 7).all()

@@ -323,13 +323,7 @@ def test_full_size_sdxl_unet_vs_fp32_oracle_on_gpu():
 
 
 # ------------------------------------------------------------------------------------------------ headline sizes
-@pytest.fixture(scope="module")
-def sdxl_weights():
-    """the real SDXL-base parameter shapes (2.57 B), synthetic values, built once for the headline-size tests."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    from tweediemix_amd import unet as U, weights as Wt
-    return Wt.synthetic_state_dict(U.SDXL, seed=1234, device="cuda", dtype=torch.float32)
+# (`sdxl_weights`: the session fixture of tests/conftest.py -- the real SDXL-base parameter shapes, synthetic values)
 
 
 def _oracle_concepts(kind, con):
@@ -345,11 +339,12 @@ def _oracle_concepts(kind, con):
     return UO.Concepts("lora", lora=lo)
 
 
-def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged"):
-    """the fusion-phase UNet plan EXACTLY as bench.py's timed region builds it: bench.build_sampler's Tweediemix (same flags,
-    prompt rows uncond + K concepts, concept routing, `streams` launch chains, shipped tile table) -> tw.plan("fusion"), i.e.
-    sampler.Tweediemix._build_plan: one UNetPlan at B = 4 with routed row_sets for streams = 1 (the default), a PlanGroup of
-    two B = 2 chains for streams = 2.  Returns (plan, ehs, pooled, time_ids, concept state dicts)."""
+def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged", call_kind="fusion", n_seeds=1):
+    """a UNet plan EXACTLY as bench.py's timed regions build it: bench.build_sampler's Tweediemix (same flags, concept routing,
+    `streams` launch chains, `n_seeds` co-batched trajectories, shipped tile table) -> tw.plan(call_kind), i.e.
+    sampler.Tweediemix._build_plan.  call_kind "fusion" (the headline step: uncond + K concept rows, routed), "fusion_base" (the LoRA
+    window's off-by-one step at t_stop: same rows, base weights), "start" (uncond, multi, K - 1 single-concept rows; un-routed) or
+    "plain" (the B = 2 CFG pair).  Returns (plan, ehs, pooled, time_ids, concept state dicts); the prompt rows are ONE seed's (co-batched seeds repeat them)."""
     from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
     cfg, K = U.SDXL, 3
     con = Wt.synthetic_concepts(cfg, kind, K, device="cuda")
@@ -361,12 +356,18 @@ def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged"):
     conf = S.make_config(guidance_scale=0.8, n_timesteps=50, t_cond=0.2, t_stop=0.8, resampling_steps=10, jumping_steps=5,
                          resolution_h=res, resolution_w=res, seed=0)
     tw = S.Tweediemix(conf, W, te, ts, lambda x0: M.build_masks(M.random_rectangle_masks(K, res, res, seed=1), hw, hw, "cuda"),
-                      concept_num=K, lora=(kind == "lora"), use_graphs=True, n_seeds=1, n_streams=streams, fp8=fp8)
+                      concept_num=K, lora=(kind == "lora"), use_graphs=True, n_seeds=n_seeds, n_streams=streams, fp8=fp8)
     tw.init_fusion(10, 40) if kind == "lora" else tw.init_fusion(10)
-    plan = tw.plan("fusion")
-    ehs = torch.cat([te[0][0:1], te[0][2:2 + K]])
-    pooled = torch.cat([te[1][0:1], te[1][2:2 + K]])
-    tid = tw.add_time_ids.repeat(K + 1, 1)
+    plan = tw.plan(call_kind)
+    if call_kind in ("fusion", "fusion_base"):           # fusion_sampling.py:324-340
+        ehs = torch.cat([te[0][0:1], te[0][2:2 + K]])
+        pooled = torch.cat([te[1][0:1], te[1][2:2 + K]])
+    elif call_kind == "start":                           # :342-359
+        ehs = torch.cat([te[0][0:2], ts[0][1:K]])
+        pooled = torch.cat([te[1][0:2], ts[1][1:K]])
+    else:                                                # :360-374
+        ehs, pooled = te[0][0:2], te[1][0:2]
+    tid = tw.add_time_ids.repeat(ehs.shape[0], 1)
     return plan, ehs, pooled, tid, con
 
 
@@ -410,6 +411,47 @@ def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, s
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
     print(f"SDXL {kind} {hw * 8}^2 B=4, {streams} chain(s), graph replay: rel_l2={r:.4g} max_rel={m:.4g} tilings={U.used_tilings(plan)}")
     assert torch.isfinite(eps).all() and r <= 2e-2 and m <= 5e-2, (r, m)
+
+
+# every OTHER call the bench line times (images_per_s, trajectory_steps_per_s, single_image): the un-routed B = 4 `start` and `fusion_base` plans, the
+# B = 2 `plain` plan (33 of a LoRA image's 75 calls; the one-workgroup-per-CU 64x160 / 32x160 tilings), and the 4-seed co-batched forms of all four
+# (B = 16 / 8, `w_period` weight sets, their own table entries) that produce the line's images/s -- bf16 and fp8
+_CALL_CASES = [(ck, ns) for ck in ("fusion", "fusion_base", "start", "plain") for ns in (1, 4) if (ck, ns) != ("fusion", 1)]
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("call_kind,n_seeds", _CALL_CASES)
+def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, call_kind, n_seeds, fp8):
+    """SDXL shapes at latent 128x128 (what bench.py times), LoRA concepts, the sampler's own plan builder for `call_kind` and `n_seeds` co-batched
+    trajectories (rows seed-major; every seed has its OWN latent), shipped tile table asserted, hipGraph replay -- against the fp32 oracle, one oracle
+    call per seed (rows of different seeds never interact).  Reference call sites: fusion_sampling.py:324-340 (fusion rows), :342-359 (start rows),
+    :360-374,406,440 (B = 2 calls); the LoRA hooks route only inside the window and only at batch 4 (utils_lora.py:62), so `fusion_base`, `start`
+    and `plain` run the base weights.  Bound: the one of every whole-UNet test (rel L2 <= 2e-2, max-abs <= 5e-2 max|ref|), per seed."""
+    from oracle import unet_oracle as UO
+    from tweediemix_amd import unet as U
+    hw = 128
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, "lora", hw, 1, fp8=fp8, call_kind=call_kind, n_seeds=n_seeds)
+    rows = ehs.shape[0]
+    routed = call_kind == "fusion"
+    assert plan.B == rows * n_seeds and plan.routed == routed and plan.fp8 == fp8
+    _ok, bad = U.tilings_follow_table(plan)
+    deviating = [b for b in bad if b[2] is not None]     # bench.py's own assertion: a shape the shipped table holds runs the table's tiling
+    assert not deviating, deviating[:5]
+    g = torch.Generator().manual_seed(6)
+    xs = torch.randn(n_seeds, 1, 4, hw, hw, generator=g)
+    x = xs.repeat(1, rows, 1, 1, 1).reshape(n_seeds * rows, 4, hw, hw).cuda()
+    eps = _graph_replay(plan, x, 601)
+    orc = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts("lora", con))
+    worst = (0.0, 0.0)
+    for s in range(n_seeds):
+        sl = slice(s * rows, (s + 1) * rows)
+        ref = orc.forward(x[sl], 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=routed)
+        r = rel_l2(eps[sl], ref)
+        m = (eps[sl] - ref).abs().max().item() / ref.abs().max().item()
+        worst = (max(worst[0], r), max(worst[1], m))
+        assert torch.isfinite(eps[sl]).all() and r <= 2e-2 and m <= 5e-2, (call_kind, n_seeds, s, r, m)
+    print(f"SDXL lora 1024^2 {call_kind} x {n_seeds} seed(s) (B={plan.B}) fp8={fp8}, graph replay: worst seed rel_l2={worst[0]:.4g} "
+          f"max_rel={worst[1]:.4g} tilings={U.used_tilings(plan)}")
 
 
 def test_low_rank_lora_full_size_sdxl_vs_oracle(sdxl_weights):

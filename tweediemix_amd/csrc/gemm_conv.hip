@@ -53,7 +53,9 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         cfg = (cfg == 17 || (cfg != 16 && (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch < 160)) ? 17 : 16;
         if (f8 == 2 && cfg == 16 && p.K / 32 > f8_block_cap(256)) cfg = 17;    // the tile's block scales stay in LDS beside the ring
         // the consumers of row_stats_out were told the partial count of the REQUESTED tiling (tmix_gemm_stats_parts): never change the width under them
-        if (p.stats_out && asked != cfg) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg %d cannot run this launch (K / 32 = %d block scales per row exceed the 256x256 tile's LDS budget); "
+        int abm = 0, abn = 0, cbm = 0, cbn = 0;
+        tmix_gemm_tile_shape(asked, &abm, &abn); tmix_gemm_tile_shape(cfg, &cbm, &cbn);
+        if (p.stats_out && abn != cbn) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: tile_cfg %d cannot run this launch (K / 32 = %d block scales per row exceed the 256x256 tile's LDS budget); "
                                                                 "with row_stats_out request tile_cfg 17 explicitly", asked, p.K / 32);
     }
     if (conv && p.scaleA) {     // convolution on e4m3 operands: the 128 x 160 lock-step tilings, with two loader waves (20) or without (12)
@@ -126,7 +128,9 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     if (d->w_period < 0 || (d->w_period > 0 && (d->batch % d->w_period))) TMIX_FAIL(TMIX_ESHAPE, "gemm: w_period=%d must divide batch=%d", d->w_period, d->batch);
     Params p = {};
     p.A = (const bf16_t*)d->A; p.lda = d->lda; p.strideA = d->strideA;
-    p.w_period = d->w_period > 0 ? d->w_period : 0; p.w_groups = d->w_period > 0 ? d->batch / d->w_period : 1;
+    // (w_period == batch is "every slice its own set": the plain strideW walk -- one group would make the magic divisor wrap to 1)
+    const int wper = (d->w_period > 0 && d->w_period < d->batch) ? d->w_period : 0;
+    p.w_period = wper; p.w_groups = wper ? d->batch / wper : 1;
     p.w_magic = (unsigned)((1ull << 32) / (unsigned)p.w_groups) + 1u;
     if (d->batch > 65535) TMIX_FAIL(TMIX_ESHAPE, "gemm: batch=%d exceeds the grid's 65535 slices", d->batch);
     p.W = (const bf16_t*)d->W; p.ldw = d->ldw; p.strideW = d->strideW;
