@@ -188,7 +188,7 @@ def test_tweedie_step_rejects_bad_args(ops):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 256, 2048), (200, 320, 320),
                                    (1024, 1280, 640), (130, 132, 192), (512, 512, 64)])
 def test_gemm_plain(ops, M, N, K, cfg):
@@ -197,7 +197,7 @@ def test_gemm_plain(ops, M, N, K, cfg):
     close(out, a.float() @ w.float().T)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
 def test_gemm_epilogues(ops, cfg):
     M, N, K = 384, 640, 256
     a, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
@@ -662,7 +662,7 @@ def test_concat_and_embedding_and_linear_small(ops):
         torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 7, 8, 9, 10, 13, 14, 15, 20, 21, 22, 23])
 def test_gemm_fused_layernorm_pair(ops, cfg):
     """producer GEMM emits row statistics of what it stored, consumer GEMM applies LayerNorm algebraically:
     together == Linear2(LayerNorm(Linear1(a) + res)) of diffusers' BasicTransformerBlock."""
@@ -1061,7 +1061,7 @@ def test_lora_down_fills_the_pad_columns(ops, P, ln):
 
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4, 7, 12, 13, 14, 16, 17, 19, 20, 21])
+@pytest.mark.parametrize("cfg", [0, 2, 4, 7, 12, 13, 14, 16, 17, 19, 20, 21, 23])
 def test_gemm_periodic_weight_sets_equal_the_gathered_form(ops, cfg):
     """tmix_gemm_desc.w_period: a batch of seeds x (1 + K) rows against 1 + K stored weight sets (slice b reads set b % P) is the same launch,
     bit for bit, as the one over per-row gathered copies of the weights -- plain, with per-set bias + residual, with the folded LayerNorm
@@ -1139,3 +1139,52 @@ def test_gemm_period_equal_to_the_batch_is_the_plain_strided_walk(ops, period):
     torch.cuda.synchronize()
     assert torch.equal(out, want)
     assert (guard[0] == 7).all() and (guard[-1] == 7).all()
+
+
+# --------------------------------------------------------------------------- tiling 23 (gemm_w22.hip): 128 x 160 over 2 x 2 waves of 64 x 80
+@pytest.mark.parametrize("M,N,K,batch", [(4096, 1280, 1280, 1), (1024, 1280, 1280, 4), (300, 640, 2560, 1), (16384, 640, 640, 1), (77, 160, 64, 2), (129, 320, 192, 3)])
+def test_gemm_w22_bias_residual_statistics_and_folded_layernorm(ops, M, N, K, batch):
+    """every epilogue flavour the 2 x 2 kernel carries, on the shapes it is shipped for (attention out-projections, attn2 to_q, FF2) and on ragged
+    ones (M not a multiple of 128: clamped loads, predicated stores): plain; bias + residual + LayerNorm row statistics (producer side); consumer
+    of a folded LayerNorm; one weight set per batch slice.  Against fp32 products of the same bf16 operands."""
+    from tweediemix_amd.weights import fold_layernorm
+    shp = (batch, M) if batch > 1 else (M,)
+    a = rnd(*shp, K, seed=401)
+    w = rnd(*((batch,) if batch > 1 else ()), N, K, seed=402, scale=K ** -0.5)
+    ref = torch.einsum("...mk,...nk->...mn", a.float(), w.float())
+    close(ops.gemm(a, w, tile_cfg=23), ref)
+    bias = rnd(*((batch,) if batch > 1 else ()), N, seed=403, dtype=torch.float32)
+    res = rnd(*shp, N, seed=404) * 2 + 0.5
+    parts = ops.stats_parts(N, 23)
+    assert parts == N // 160
+    stats = torch.full((parts, batch * M, 2), float("nan"), device="cuda")
+    h = ops.gemm(a, w, bias=bias, residual=res, row_stats_out=stats, tile_cfg=23)
+    close(h, ref + (bias[:, None] if batch > 1 else bias) + res.float())
+    hf = h.float().reshape(batch * M, N)
+    torch.testing.assert_close(stats[:, :, 0].sum(0), hf.sum(-1), rtol=1e-5, atol=2e-3)
+    torch.testing.assert_close(stats[:, :, 1].sum(0), (hf ** 2).sum(-1), rtol=1e-5, atol=2e-3)
+    # the same launch on the four-wave tiling: identical stored values up to the accumulation order of the MFMA shapes
+    h21 = ops.gemm(a, w, bias=bias, residual=res, tile_cfg=21)
+    assert (h.float() - h21.float()).abs().max().item() <= 2 ** -7 * h21.float().abs().max().item()
+    # consumer of the folded LayerNorm over those rows (N of the producer = K of the consumer)
+    if N % 64:
+        return
+    N2 = 320
+    gamma, beta = rnd(N, seed=405, dtype=torch.float32) * 0.2 + 1, rnd(N, seed=406, dtype=torch.float32) * 0.3
+    w2, b2 = rnd(N2, N, seed=407, scale=N ** -0.5), rnd(N2, seed=408, dtype=torch.float32)
+    wp, cs, t = fold_layernorm(w2, gamma, beta, b2)
+    y = ops.gemm(h.reshape(batch * M, N), wp, bias=t, ln_stats=stats, ln_colsum=cs, tile_cfg=23)
+    close(y, F.layer_norm(hf, (N,), gamma, beta, 1e-5) @ w2.float().T + b2, rtol=2 ** -6, atol_frac=4e-3)
+
+
+def test_gemm_w22_falls_back_for_launches_it_does_not_carry(ops):
+    """GEGLU, a transposed region, an activation, a row-group bias or a width that is not a multiple of 160 run as tiling 21 / 12: same results as asking for those"""
+    from tweediemix_amd.weights import interleave_geglu
+    M, C = 256, 320
+    a = rnd(M, C, seed=411)
+    w = rnd(8 * C, C, seed=412, scale=C ** -0.5)
+    wi, _ = interleave_geglu(w, None)
+    assert torch.equal(ops.gemm(a, wi, geglu=True, tile_cfg=23), ops.gemm(a, wi, geglu=True, tile_cfg=21))
+    w2 = rnd(384, C, seed=413, scale=C ** -0.5)
+    assert torch.equal(ops.gemm(a, w2, tile_cfg=23), ops.gemm(a, w2, tile_cfg=21))
+    assert torch.equal(ops.gemm(a, w2[:320], act="gelu", tile_cfg=23), ops.gemm(a, w2[:320], act="gelu", tile_cfg=21))

@@ -1,0 +1,42 @@
+"""tiling 23 (2 x 2 waves of 64 x 80, gemm_w22.hip) against the four-wave 128 x 160 tilings on the launches it is meant for, hot (back-to-back
+replays) and cold-ish (a 256 MiB junk pass between launches), with the epilogue flavours of the transformer blocks."""
+import os, sys, ctypes as C, torch
+sys.path.insert(0, os.getcwd())
+from tweediemix_amd import ops, lib as L
+lib = L.load(); BF = torch.bfloat16
+st = torch.cuda.current_stream().cuda_stream
+junk = torch.empty(1 << 27, device="cuda", dtype=torch.int16)
+
+def hot(d, n=50):
+    for _ in range(5): lib.tmix_gemm_bf16(C.byref(d), st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): lib.tmix_gemm_bf16(C.byref(d), st)
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+def cold(d):
+    ts = []
+    for _ in range(7):
+        junk.add_(1); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); lib.tmix_gemm_bf16(C.byref(d), st); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+shapes = [("to_out / to_q 32^2", 4, 1024, 1280, 1280), ("FF2 32^2", 1, 4096, 1280, 5120), ("cube shared", 1, 4096, 1280, 1280),
+          ("proj 64^2", 1, 16384, 640, 640), ("FF2 64^2", 1, 16384, 640, 2560), ("B=16 cube", 16, 1024, 1280, 1280), ("B=2 FF2", 1, 2048, 1280, 5120)]
+for name, b, M, N, K in shapes:
+    a = torch.randn(b, M, K, device="cuda").to(BF)
+    w = (torch.randn(b, N, K, device="cuda") * K ** -0.5).to(BF) if b > 1 else (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(b, M, N, device="cuda").to(BF)
+    out = torch.empty(b, M, N, device="cuda", dtype=BF)
+    row = []
+    for cfg in (12, 20, 21, 23):
+        parts = ops.stats_parts(N, cfg)
+        stats = torch.zeros(parts, b * M, 2, device="cuda")
+        d = ops.make_gemm_desc(a, w, out, bias=bias, residual=res, row_stats_out=stats, tile_cfg=cfg)
+        row.append(f"cfg{cfg}: hot {hot(d):6.1f} cold {cold(d):6.1f}")
+    fl = 2.0 * b * M * N * K
+    print(f"{name:20s} b={b} M={M} N={N} K={K} ({fl / 1e9:.1f} GF): " + " | ".join(row), flush=True)

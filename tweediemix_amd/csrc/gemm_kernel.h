@@ -1574,7 +1574,8 @@ struct TileCfg { int bm, bn; };
 // every SIMD hosts one math wave and one loader, and a K-tile's 36 LDS-DMA instructions are nine per loader
 // 22 = 256x320 with the PHASE-OFFSET mainloop (eight waves of 64x160; bf16 GEMM only): the lock-step 256x320 loop (14) stops all eight waves at every
 // K-tile hand-over -- 79 % of the MFMA rate with the LDS-DMA ablated -- where this one keeps one wave of every SIMD in its MFMA segment
-constexpr int NUM_CFG = 22;
+// 23 = 128x160 over 2 x 2 math waves of 64x80 on v_mfma_f32_16x16x32_bf16 + four loader waves (its own kernel: gemm_w22.hip)
+constexpr int NUM_CFG = 23;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -1626,5 +1627,7 @@ int launch_group2(int cfg, int conv, int f8, Params& p, int batch, hipStream_t s
 int launch_group3(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
 int launch_group4(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
 int launch_group5(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);      // fp8 in the lock-step loops (f8 = 3: per-row A scales, 4: MX blocks)
+bool w22_eligible(const Params& p, int conv, int f8);                                   // gemm_w22.hip (tiling 23)
+int launch_w22(Params& p, int batch, hipStream_t st);
 
 }  // namespace tmix_gemm

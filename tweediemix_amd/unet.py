@@ -492,7 +492,7 @@ class UNetPlan:
             st = torch.cuda.current_stream().cuda_stream
             best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
             cands = list(L.TILE_CANDIDATES)                         # (16 / 17 and the loader-wave tilings 19 / 20 exist for the plain GEMM only)
-            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 21: 12, 22: 14}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
+            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 21: 12, 22: 14, 23: 12}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
             for _rep in range(reps):
                 for cfg in cands:
                     for _i, kind, d in tun:
@@ -1120,13 +1120,17 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
         # step's two 978-launch chains) corrupt the process heap within a few dozen replays on ROCm 7.0 ("corrupted size vs. prev_size in fastbins" /
         # "double free or corruption"; every run of tools/jobs4/r4zv_refine_video.sh), the same loop without them ran 400 re-captures clean
         import time as _time
+        # (each sample = `burst` back-to-back replays: the host launch + synchronize latency of a sample, of the order of the 20 us acceptance threshold
+        # below, is paid once per burst instead of once per replay)
         ts = []
+        burst = 3
         for _ in range(reps):
             torch.cuda.synchronize()
             t0 = _time.perf_counter()
-            g.replay()
+            for _b in range(burst):
+                g.replay()
             torch.cuda.synchronize()
-            ts.append(1e3 * (_time.perf_counter() - t0))
+            ts.append(1e3 * (_time.perf_counter() - t0) / burst)
         return sorted(ts)[len(ts) // 2]
 
     plans = _plans_of(self)
@@ -1142,7 +1146,7 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
         cur = members[k][0][2].tile_cfg
         best, best_t = cur, base
         for cfg in (cands or L.TILE_CANDIDATES):
-            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 18, 19, 21, 22)):
+            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 18, 19, 21, 22, 23)):
                 continue
             for p, _kind, d in members[k]:
                 d.tile_cfg = cfg
