@@ -192,6 +192,16 @@ int tmix_gemm_prefetch_next(const void* next_weights, int64_t bytes, void* strea
 enum { TMIX_F8_A_BLOCK_SCALES = 1, TMIX_F8_GEGLU_OUT = 2, TMIX_F8_COPY_OUT = 4 };
 #define TMIX_COLSTATS_ROWS 32   /* rows per partial of col_stats_out */
 int tmix_gemm_fp8(const tmix_gemm_desc* d, const uint8_t* scale_a, const uint8_t* scale_w, void* stream);
+/* attn2 of a BasicTransformerBlock in ONE launch: q = to_q(LayerNorm(h)) and softmax(q K^T * scale) V against the cached prompt keys -- the patched
+ * cross-attention forward of utils_custom.py:56-106 / utils_lora.py:65-69,101-111 (per-row concept weights = per-slice weight sets of d) without the q
+ * round trip through memory and without the second launch.  d describes the projection exactly as for tmix_gemm_bf16 (A = hidden state rows, W = to_q
+ * weight(s), bias, folded LayerNorm via ln_stats / ln_colsum, batch / strideW / w_period; no residual, activation, transposed region or statistics;
+ * d->C is not written and may be NULL); N = heads * 64 must be a multiple of 320 (five heads per tile), K %% 64 == 0.  K: cached keys
+ * [images][Skv][ldk] (head h at columns h*64..), Vt: cached V^T [images][N][ldvt] with ldvt == 80 (zero behind Skv), Skv <= 80; image of row r of
+ * slice b = b * (M / rows_per_image) + r / rows_per_image (rows_per_image %% 64 == 0: the latent's token count).  O [batch * M][ldo] bf16 receives the
+ * attention output (head h at columns h*64..), the A operand of attn2.to_out. */
+int tmix_gemm_q_cross_attn(const tmix_gemm_desc* d, const void* K, int64_t ldk, int64_t strideK, const void* Vt, int64_t ldvt, int64_t strideVt,
+                           void* O, int64_t ldo, int rows_per_image, int Skv, float scale, void* stream);
 /* Row quantiser for tmix_gemm_fp8: X bf16 [rows][ld] -> Q e4m3 [rows][ldq] and scale_e8m0[r] = the smallest exponent that brings
  * max|X[r]| under 448 (K %% 8 == 0, K <= 8192).  Used on activations before each fp8 GEMM and once on the weights. */
 int tmix_quantize_fp8_rows(const void* X, int64_t ld, void* Q, int64_t ldq, uint8_t* scale_e8m0, int64_t rows, int K, void* stream);

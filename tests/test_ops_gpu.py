@@ -1188,3 +1188,79 @@ def test_gemm_w22_falls_back_for_launches_it_does_not_carry(ops):
     w2 = rnd(384, C, seed=413, scale=C ** -0.5)
     assert torch.equal(ops.gemm(a, w2, tile_cfg=23), ops.gemm(a, w2, tile_cfg=21))
     assert torch.equal(ops.gemm(a, w2[:320], act="gelu", tile_cfg=23), ops.gemm(a, w2[:320], act="gelu", tile_cfg=21))
+
+
+# --------------------------------------------------------------------------- attn2 in one launch (gemm_qattn.hip)
+def _qattn_ref(a, w, bias, k, vt, rows_per_image, scale, ln=None):
+    """fp32 reference: q = [LN](a) w^T + bias per batch slice, then softmax(q K^T scale) V per 64-wide head against the image's cached keys"""
+    af = a.float()
+    if ln is not None:
+        af = F.layer_norm(af, (af.shape[-1],), ln[0], ln[1], 1e-5)
+    a3 = af if af.dim() == 3 else af.unsqueeze(0)
+    w3 = w.float() if w.dim() == 3 else w.float().unsqueeze(0)
+    q = torch.einsum("bmk,bnk->bmn", a3, w3.expand(a3.shape[0], -1, -1) if w3.shape[0] == 1 else w3[torch.arange(a3.shape[0]) % w3.shape[0]])
+    if bias is not None:
+        b2 = bias if bias.dim() == 2 else bias.unsqueeze(0)
+        q = q + (b2.expand(a3.shape[0], -1) if b2.shape[0] == 1 else b2[torch.arange(a3.shape[0]) % b2.shape[0]])[:, None]
+    q = q.to(BF).float()                                    # the two-launch form stores q in bf16
+    Bz, M, N = q.shape
+    H, Skv = N // 64, k.shape[1]
+    q = q.reshape(Bz * M // rows_per_image, rows_per_image, H, 64).transpose(1, 2)
+    kk = k.float().reshape(k.shape[0], Skv, H, 64).transpose(1, 2)
+    vv = vt.float()[:, :, :Skv].reshape(vt.shape[0], H, 64, Skv).transpose(2, 3)
+    o = F.scaled_dot_product_attention(q, kk, vv, scale=scale)
+    return o.transpose(1, 2).reshape(Bz, M, N) if a.dim() == 3 else o.transpose(1, 2).reshape(M, N)
+
+
+@pytest.mark.parametrize("B,S,C,Skv,routed,ln", [(4, 1024, 1280, 77, True, True), (4, 1024, 1280, 77, False, True), (2, 4096, 640, 77, False, True),
+                                                   (1, 128, 320, 80, False, False), (3, 192, 320, 5, True, True), (2, 64, 640, 33, False, False)])
+def test_q_projection_and_cross_attention_in_one_launch(ops, B, S, C, Skv, routed, ln):
+    """tmix_gemm_q_cross_attn against the fp32 reference AND against the two launches it replaces (tmix_gemm_bf16 -> tmix_attn_fwd) on the shapes of
+    the SDXL plan (32 x 32 and 64 x 64 levels, LoRA-routed per-row weights and shared weights, LayerNorm folded into to_q) and on small / ragged ones
+    (one to 80 keys, three images, no LayerNorm)."""
+    from tweediemix_amd.weights import fold_layernorm
+    h = rnd(B, S, C, seed=501) * 1.5 + 0.3
+    P = B if routed else 1
+    wq = rnd(P, C, C, seed=502, scale=C ** -0.5)
+    bq = rnd(P, C, seed=503, dtype=torch.float32) * 0.1
+    k = rnd(B, Skv, C, seed=504)
+    vt = torch.zeros(B, C, 80, device="cuda", dtype=BF)
+    vt[:, :, :Skv] = rnd(B, C, Skv, seed=505)
+    scale = 64 ** -0.5
+    kw = {}
+    lnp = None
+    if ln:
+        gamma, beta = rnd(C, seed=506, dtype=torch.float32) * 0.2 + 1, rnd(C, seed=507, dtype=torch.float32) * 0.3
+        lnp = (gamma, beta)
+        fold = [fold_layernorm(wq[i], gamma, beta, bq[i]) for i in range(P)]
+        wp, cs, t = [torch.stack([f[j] for f in fold]).contiguous() for j in range(3)]
+        hf = h.float()
+        stats = torch.stack([hf.sum(-1), (hf ** 2).sum(-1)], -1).view(1, B * S, 2).contiguous()
+        kw = dict(ln_stats=stats, ln_colsum=cs if routed else cs[0])
+        w_used, b_used = (wp, t) if routed else (wp[0], t[0])
+    else:
+        w_used, b_used = (wq, bq) if routed else (wq[0], bq[0])
+    a = h if routed else h.view(B * S, C)
+    got = ops.gemm_q_cross_attn(a, w_used, k, vt, S, scale, bias=b_used, **kw)
+    ref = _qattn_ref(a, wq if routed else wq[0], bq if routed else bq[0], k, vt, S, scale, lnp)
+    close(got, ref, rtol=2 ** -6, atol_frac=6e-3)
+    # the two-launch form on the same operands
+    q = ops.gemm(a, w_used, bias=b_used, **kw)
+    two = ops.attention(q.view(B, S, C), k, vt, C // 64, Skv, scale)
+    d = (got.float().view(B, S, C) - two.float()).abs().max().item()
+    assert d <= 2 ** -6 * two.float().abs().max().item() + 1e-3, d
+
+
+def test_q_cross_attention_rejects_what_it_does_not_carry(ops):
+    import ctypes as C_
+    from tweediemix_amd import lib as L
+    a, w = rnd(128, 320, seed=511), rnd(320, 320, seed=512)
+    k, vt = rnd(1, 77, 320, seed=513), torch.zeros(1, 320, 80, device="cuda", dtype=BF)
+    out = torch.empty(128, 320, device="cuda", dtype=BF)
+    lib = L.load()
+    d = ops.make_gemm_desc(a, w, None, residual=out)
+    assert lib.tmix_gemm_q_cross_attn(C_.byref(d), *ops.q_cross_attn_args(k, vt, out, 128, 0.125), None) == L.EINVAL
+    d = ops.make_gemm_desc(a, rnd(256, 320, seed=514), None)          # four heads: not a multiple of the five-head tile
+    assert lib.tmix_gemm_q_cross_attn(C_.byref(d), *ops.q_cross_attn_args(k[:, :, :256], vt[:, :256], out[:, :256], 128, 0.125), None) == L.ESHAPE
+    d = ops.make_gemm_desc(a, w, None)
+    assert lib.tmix_gemm_q_cross_attn(C_.byref(d), *ops.q_cross_attn_args(k, vt, out, 96, 0.125), None) == L.ESHAPE     # rows_per_image % 64

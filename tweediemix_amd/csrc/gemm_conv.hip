@@ -106,7 +106,7 @@ extern "C" int tmix_gemm_stats_parts(int N, int tile_cfg) {
 }
 
 // fp8 = true: A / W hold OCP e4m3 bytes with one E8M0 scale per row (tmix_gemm_fp8); everything behind the main loop is shared
-static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, const uint8_t* scaleW, void* stream) {
+static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, const uint8_t* scaleW, void* stream, const QAExtra* qa = nullptr) {
     if (!d || !d->A || !d->W) TMIX_FAIL(TMIX_EINVAL, "gemm: null descriptor/operand");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) TMIX_FAIL(TMIX_ESHAPE, "gemm: empty problem M=%d N=%d K=%d batch=%d", d->M, d->N, d->K, d->batch);
     if (d->K % BK) TMIX_FAIL(TMIX_ESHAPE, "gemm: K=%d must be a multiple of %d", d->K, BK);
@@ -117,7 +117,7 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     if (!aligned16(d->A) || !aligned16(d->W)) TMIX_FAIL(TMIX_EALIGN, "gemm: A/W must be 16-byte aligned");
     const bool has_trans = d->n_trans_begin >= 0 && d->n_trans_begin < d->N;
     if (has_trans && (!d->Ct || (d->n_trans_begin % 128))) TMIX_FAIL(TMIX_EINVAL, "gemm: transposed region needs Ct and n_trans_begin %% 128 == 0");
-    if ((!has_trans || d->n_trans_begin > 0) && !d->C) TMIX_FAIL(TMIX_EINVAL, "gemm: null C");
+    if ((!has_trans || d->n_trans_begin > 0) && !d->C && !qa) TMIX_FAIL(TMIX_EINVAL, "gemm: null C");
     if (d->C && ((d->ldc % 4) || (((uintptr_t)d->C) & 7) || (d->strideC % 4))) TMIX_FAIL(TMIX_EALIGN, "gemm: C must be 8-byte aligned with ldc %% 4 == 0");
     if (d->residual && ((d->ldr % 4) || (((uintptr_t)d->residual) & 7))) TMIX_FAIL(TMIX_EALIGN, "gemm: residual alignment");
     if (d->bias && (((uintptr_t)d->bias) & 15)) TMIX_FAIL(TMIX_EALIGN, "gemm: bias must be 16-byte aligned");
@@ -199,7 +199,20 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     if (p.f8out && !(p.wide & 2)) TMIX_FAIL(TMIX_EINVAL, "gemm_fp8: e4m3 GEGLU output needs the staged epilogue");
     if (p.f8copy && !(p.wide & 1)) TMIX_FAIL(TMIX_EALIGN, "gemm: the e4m3 copy needs the staged epilogue (16-byte aligned C / residual rows, N %% 8 == 0)");
     if (fp8 && has_trans && !(p.wide & 4)) TMIX_FAIL(TMIX_EALIGN, "gemm_fp8: the transposed region needs a 16-byte aligned Ct with ldct %% 8 == 0");
+    if (qa) return launch_qattn(p, *qa, d->batch, (hipStream_t)stream);
     return launch(0, p, d->batch, d->tile_cfg, (hipStream_t)stream);
+}
+
+// attn2.to_q (the projection described by d: A = hidden state rows, W = to_q weight, bias / folded LayerNorm as in tmix_gemm_bf16; d->C is not written) and
+// the cross-attention of its output against cached K [images][Skv][ldk] / V^T [images][N][ldvt = 80] in one launch: O [batch * M][ldo] receives
+// softmax(q K^T * scale) V per 64-wide head.  rows_per_image: consecutive rows of A that share an image's keys (the latent's token count).
+extern "C" int tmix_gemm_q_cross_attn(const tmix_gemm_desc* d, const void* K, int64_t ldk, int64_t strideK, const void* Vt, int64_t ldvt, int64_t strideVt,
+                                      void* O, int64_t ldo, int rows_per_image, int Skv, float scale, void* stream) {
+    if (!d) TMIX_FAIL(TMIX_EINVAL, "gemm_q_cross_attn: null descriptor");
+    if (d->reserved0 || d->residual || d->row_stats_out || d->col_stats_out || d->rowgroup_bias || d->epilogue != TMIX_EPI_NONE || (d->n_trans_begin >= 0 && d->n_trans_begin < d->N))
+        TMIX_FAIL(TMIX_EINVAL, "gemm_q_cross_attn: the projection takes a bias and a folded LayerNorm only");
+    const QAExtra x = {K, ldk, strideK, Vt, ldvt, strideVt, O, ldo, rows_per_image, Skv, scale};
+    return gemm_entry(d, false, nullptr, nullptr, stream, &x);
 }
 
 extern "C" int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream) { return gemm_entry(d, false, nullptr, nullptr, stream); }

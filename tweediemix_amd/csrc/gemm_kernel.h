@@ -1629,5 +1629,8 @@ int launch_group4(int cfg, int conv, int f8, Params& p, int batch, hipStream_t s
 int launch_group5(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);      // fp8 in the lock-step loops (f8 = 3: per-row A scales, 4: MX blocks)
 bool w22_eligible(const Params& p, int conv, int f8);                                   // gemm_w22.hip (tiling 23)
 int launch_w22(Params& p, int batch, hipStream_t st);
+// gemm_qattn.hip: attn2.to_q + the cross-attention behind it in one launch (tmix_gemm_q_cross_attn)
+struct QAExtra { const void* K; int64_t ldk, strideK; const void* Vt; int64_t ldvt, strideVt; void* O; int64_t ldo; int rows_per_image, Skv; float scale; };
+int launch_qattn(Params& p, const QAExtra& x, int batch, hipStream_t st);
 
 }  // namespace tmix_gemm

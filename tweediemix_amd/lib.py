@@ -69,6 +69,7 @@ SIGNATURES = {
     "tmix_gemm_bf16": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "tmix_gemm_prefetch_next": (C.c_int, [vp, i64, vp]),
     "tmix_gemm_fp8": (C.c_int, [C.POINTER(GemmDesc), vp, vp, vp]),
+    "tmix_gemm_q_cross_attn": (C.c_int, [C.POINTER(GemmDesc), vp, i64, i64, vp, i64, i64, vp, i64, C.c_int, C.c_int, f32, vp]),
     "tmix_quantize_fp8_rows": (C.c_int, [vp, i64, vp, i64, vp, i64, C.c_int, vp]),
     "tmix_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "tmix_conv3x3_nhwc_fp8": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp]),

@@ -187,6 +187,26 @@ def gemm(a, w, out=None, f8_copy=None, **kw):
     return out if out is not None else kw.get("out_f32")
 
 
+def q_cross_attn_args(k, vt, out, rows_per_image, scale):
+    """the arguments of tmix_gemm_q_cross_attn behind its descriptor: cached K [images, Skv, C], V^T [images, C, 80], output [rows, C]"""
+    assert k.dtype == BF16 and vt.dtype == BF16 and out.dtype == BF16 and k.stride(2) == 1 and vt.stride(2) == 1 and out.stride(-1) == 1
+    o2 = out.reshape(-1, out.shape[-1])
+    assert o2.data_ptr() == out.data_ptr()
+    return (k.data_ptr(), k.stride(1), k.stride(0), vt.data_ptr(), vt.stride(1), vt.stride(0), o2.data_ptr(), o2.stride(0),
+            int(rows_per_image), int(k.shape[1]), float(scale))
+
+
+def gemm_q_cross_attn(a, w, k, vt, rows_per_image, scale, out=None, **kw):
+    """attn2 in one launch (tmix_gemm_q_cross_attn): softmax((a @ w^T [+ bias, folded LayerNorm]) K^T * scale) V per 64-wide head.
+    a [batch?, M, C], w [batch?, C, C]; k [images, Skv <= 80, C], vt [images, C, 80]; returns the attention output [batch?, M, C]."""
+    _need_cuda(a, w, k, vt)
+    if out is None:
+        out = torch.empty(*a.shape[:-1], w.shape[-2], device=a.device, dtype=BF16)
+    d = make_gemm_desc(a, w, None, **kw)
+    L.check(L.load().tmix_gemm_q_cross_attn(C.byref(d), *q_cross_attn_args(k, vt, out, rows_per_image, scale), _stream()), "tmix_gemm_q_cross_attn")
+    return out
+
+
 def quantize_fp8_rows(x, q=None, scale=None):
     """x bf16 [..., K] (rows contiguous in K) -> (q uint8 [..., K] holding OCP e4m3 bytes, scale uint8 [...] E8M0 exponents):
     x[r] ~= e4m3(q[r]) * 2^(scale[r] - 127)."""

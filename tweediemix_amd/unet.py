@@ -454,6 +454,9 @@ class UNetPlan:
         # conv_shortcut rides in conv2's K loop (tmix_conv_desc.S1 / S2): no shortcut GEMM, and the up-blocks' concatenations are never written
         # (TMIX_SHORTCUT_GEMM=1: the separate GEMM + concat launches)
         self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")
+        # attn2.to_q and the 77-key cross-attention behind it as ONE launch (tmix_gemm_q_cross_attn: no q round trip, 70 launches fewer per call); bf16 plans
+        # with the merged / shared weights, five-head tiles (C % 320 == 0), <= 80 cached keys (TMIX_NO_QATTN=1: the two-launch form)
+        self._qattn = not os.environ.get("TMIX_NO_QATTN") and not self.fp8 and not self.lowrank and kv.Lk <= 80 and kv.ld == 80
         self._tunable = []                  # (index into self.ops, kind, descriptor) of every GEMM / conv launch
         self._ln_links = []                 # (producer desc, [consumer descs]): ln_parts follows the producer's tiling
         self._build()
@@ -733,6 +736,27 @@ class UNetPlan:
             for c in cons:
                 c.ln_parts = parts
 
+    def _q_attn(self, h, key, k, vt, ao, S, Cc, ln):
+        """attn2: to_q (LayerNorm folded, per-row merged weights when LoRA-routed) + cross-attention against the cached K / V^T in one launch"""
+        W = self.W
+        shp = (self.B, S) if self.routed else (self.B * S,)
+        kw = {"ln_stats": ln, "ln_colsum": self._rows(key, ".colsum") if self.routed else W[key + ".colsum"],
+              "bias": self._rows(key, ".bias") if self.routed else W[key + ".bias"]}
+        w = self._rows(key) if self.routed else W[key]
+        d = ops.make_gemm_desc(h.view(*shp, Cc), w, None, **kw)
+        self._ln_links[-1][1].append(d)
+        args = ops.q_cross_attn_args(k, vt, ao, S, self.cfg.head_dim ** -0.5)
+        self.keep += [d, k, vt, ao]
+        self._hint_weights(w)
+        self._emit(self.lib.tmix_gemm_q_cross_attn, C.byref(d), *args)
+        fl = 2 * d.M * d.N * d.K * d.batch
+        fla = 4 * self.B * (Cc // 64) * S * k.shape[1] * 64
+        self.flops += fl + fla
+        self.gemm_flops += fl
+        self.launches["gemm"].append((d, fl))
+        self.op_meta[len(self.ops) - 1] = ("gemm", fl + fla, d)
+        return ao
+
     def _attn(self, q, k, vt, out, H, Sq, Skv, f8_out=None):
         """f8_out: an ops.F8Copy that receives the output as e4m3 + MX block scales instead of the bf16 tensor `out` (fp8 plans: the out-projection's
         A operand without a quantiser launch and with half the bytes)"""
@@ -907,9 +931,18 @@ class UNetPlan:
                 self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
                 A.put(ao_full)
             # --- cross attention against the cached K / V^T; norm2 folded into to_q
-            q = A.get(B, S, Cc)
-            self._proj(h, a2 + ".q", q, S, Cc, ln=st, fp8=h8 is not None, a8=h8, a_full=h_full)
-            if ao8 is not None:
+            if getattr(self, "_qattn", False) and Cc % 320 == 0 and S % 64 == 0:
+                ao = A.get(B, S, Cc)
+                self._q_attn(h, a2 + ".q", self.kv.k[a2], self.kv.vt[a2], ao, S, Cc, st)
+                self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao)
+                A.put(ao)
+                q = None
+            else:
+                q = A.get(B, S, Cc)
+                self._proj(h, a2 + ".q", q, S, Cc, ln=st, fp8=h8 is not None, a8=h8, a_full=h_full)
+            if q is None:
+                pass
+            elif ao8 is not None:
                 self._attn(q, self.kv.k[a2], self.kv.vt[a2], None, H, S, self.kv.Lk, f8_out=ao8)
                 A.put(q)
                 self._proj(ao8.q.view(B, S, Cc), a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, fp8=True, a8=ao8)
