@@ -11,7 +11,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${ta
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o ${tag}_fp8 -- python bench.py --dtype fp8 $BARGS > $out/${tag}_fp8_bench_line.json 2> $out/bench_fp8.log
 for pm in FETCH_SIZE WRITE_SIZE; do
   # (each counter pass under its own timeout: a pass that hangs costs its own evidence, not the others')
-  timeout 600 rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_$pm.log 2>&1
+  timeout 240 rocprofv3 --pmc $pm --kernel-trace --output-format csv -d $out -o ${tag}_$pm -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_$pm.log 2>&1
 done
 python - $out $tag <<'PY'
 import csv, sys, json, collections, re
@@ -23,7 +23,7 @@ for pm in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != pm: continue
         n = r["Kernel_Name"]
         m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
-        key = ("conv" if m.group(1).split(",")[5].strip() == "1" else "gemm") if m else "attn" if ("attn_fwd" in n or "attn_small" in n) else "norm" if "gn_" in n else None
+        key = ("conv" if m.group(1).split(",")[5].strip() == "1" else "gemm") if m else "gemm" if ("gemm_qattn_kernel" in n or "gemm_w22_kernel" in n) else "attn" if ("attn_fwd" in n or "attn_small" in n) else "norm" if "gn_" in n else None
         if key:
             agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
     res[pm] = {k: {"launches": v[0], "sum_kb": v[1], "avg_kb_per_launch": v[1] / max(1, v[0])} for k, v in agg.items()}
@@ -36,7 +36,7 @@ for k in res["FETCH_SIZE"]:
 json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(summary))
 PY
-timeout 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_MFMA.log 2>&1
+timeout 240 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $out -o ${tag}_MFMA -- python bench.py --steps 2 --warmup 1 --no-graphs $BARGS > $out/pmc_MFMA.log 2>&1
 python - $out $tag <<'PY'
 import csv, sys, json, collections, re
 out, tag = sys.argv[1], sys.argv[2]
@@ -51,7 +51,7 @@ for r in csv.DictReader(open(f"{out}/{tag}_MFMA_counter_collection.csv")):
     if r["Counter_Name"] != "MfmaUtil": continue
     n = r["Kernel_Name"]
     m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
-    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else None
+    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "gemm<qattn:64x320,to_q+cross-attention>" if "gemm_qattn_kernel" in n else "gemm<w22:128x160,2x2>" if "gemm_w22_kernel" in n else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else None
     if key: agg[key].append((float(r["Counter_Value"]), dur.get(r["Dispatch_Id"], 1.0)))
 cls = collections.defaultdict(list)
 for k, v in agg.items(): cls[k.split("<")[0]] += v

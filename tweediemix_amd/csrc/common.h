@@ -140,3 +140,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+// The same over a (tiles, slices) grid: workgroups are dispatched x-fastest and dealt to the XCDs round robin by their LINEAR id, so a remap of blockIdx.x
+// alone gives every XCD a few tiles of EVERY slice -- with one weight set per slice (concept-routed LoRA rows) each XCD then pulls all the sets and every
+// slice's A rows through the fabric (routed 1280-cube: 55 MB of operand traffic per launch chip-wide).  Remapping the linear id over the whole grid gives an XCD
+// one contiguous run of (slice, tile) ids: half a slice per XCD at B = 4 (34 MB).  bid = tile id inside the slice, by = slice.
+__device__ __forceinline__ void xcd_remap_grid(int& bid, int& by) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if (gy == 1) { bid = xcd_remap(blockIdx.x, gx); by = blockIdx.y; return; }
+    const int lg = xcd_remap(blockIdx.y * gx + blockIdx.x, gx * gy);
+    by = lg / gx; bid = lg - by * gx;
+}

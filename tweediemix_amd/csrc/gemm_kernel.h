@@ -225,7 +225,12 @@ gemm_conv_kernel(const Params p) {
     // Tile order: each XCD (private 4 MiB L2) owns a contiguous range of logical ids, and ids sweep GM tile-rows
     // per tile-column, so the ~64 tiles resident on an XCD at any time form a compact GM x (64/GM) patch that
     // shares GM A-panels and 64/GM W-panels instead of streaming one W-panel per tile through the L2.
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef TMIX_XCD_X_ONLY     // dev A/B builds: the remap of blockIdx.x alone (every XCD works on every slice)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), by = blockIdx.y;
+#else
+    int bid, by;
+    xcd_remap_grid(bid, by);
+#endif
     const int per_group = p.group_m * p.tiles_n;
     const int grp = bid / per_group;
     const int first_m = grp * p.group_m;
@@ -236,7 +241,6 @@ gemm_conv_kernel(const Params p) {
     const int m0l = (ABL & 1) ? 0 : m0, n0l = (ABL & 1) ? 0 : n0;      // rows the STAGING reads (ablation bit 0: tile (0, 0))
     // periodic weight sets (co-batched seeds: rows [seed][concept] share the concept's weights): slices that read the same W are issued back to back
     // (by / w_groups as a multiply-high by the host's reciprocal: scalar instructions only, exact for by, w_groups < 65536)
-    const int by = blockIdx.y;
     const int bzw = p.w_period > 0 ? (int)__umulhi((unsigned)by, p.w_magic) : by;       // == bz % w_period
     const int bz = p.w_period > 0 ? (by - bzw * p.w_groups) * p.w_period + bzw : by;
 

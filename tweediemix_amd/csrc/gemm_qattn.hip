@@ -67,7 +67,8 @@ __global__ void __launch_bounds__((Q_NW + Q_LW) * 64, 2) gemm_qattn_kernel(const
             if (u < per && ln < lines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_keep[u]) : "v"(p.pf + (ln << 7)) : "memory");
         }
     }
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid, by;
+    xcd_remap_grid(bid, by);
     const int per_group = p.group_m * p.tiles_n;
     const int grp = bid / per_group;
     const int first_m = grp * p.group_m;
@@ -75,7 +76,6 @@ __global__ void __launch_bounds__((Q_NW + Q_LW) * 64, 2) gemm_qattn_kernel(const
     const int rem = bid - grp * per_group;
     const int tile_n = rem / gsize, tile_m = first_m + (rem - tile_n * gsize);
     const int m0 = tile_m * Q_BM, n0 = tile_n * Q_BN;
-    const int by = blockIdx.y;
     const int bzw = p.w_period > 0 ? (int)__umulhi((unsigned)by, p.w_magic) : by;
     const int bz = p.w_period > 0 ? (by - bzw * p.w_groups) * p.w_period + bzw : by;
     const bf16_t* Ab = p.A + (int64_t)bz * p.strideA;

@@ -58,7 +58,8 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
         }
     }
     // tile order: gemm_kernel.h's (each XCD owns a compact patch of group_m x (64 / group_m) tiles)
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid, by;
+    xcd_remap_grid(bid, by);
     const int per_group = p.group_m * p.tiles_n;
     const int grp = bid / per_group;
     const int first_m = grp * p.group_m;
@@ -66,7 +67,6 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
     const int rem = bid - grp * per_group;
     const int tile_n = rem / gsize, tile_m = first_m + (rem - tile_n * gsize);
     const int m0 = tile_m * W_BM, n0 = tile_n * W_BN;
-    const int by = blockIdx.y;
     const int bzw = p.w_period > 0 ? (int)__umulhi((unsigned)by, p.w_magic) : by;
     const int bz = p.w_period > 0 ? (by - bzw * p.w_groups) * p.w_period + bzw : by;
     const bf16_t* Ab = p.A + (int64_t)bz * p.strideA;
