@@ -275,6 +275,17 @@ def test_sidecar_gpu_is_a_physical_id_when_the_parent_restricts_the_visible_devi
     assert [M.sidecar_layout("out", r, 4, r, 1)[1] for r in range(4)] == [4, 5, 6, 7]
     assert M.sidecar_layout("out", 1, 4, 1, 9) == ("out/rank1", 9)      # an explicit GPU outside the job is passed through
     assert M.sidecar_layout("out", 0, 1, 0, 1) == ("out", 1)            # one process: the reference's own arguments
+    # ... and the child must not inherit HIP_VISIBLE_DEVICES (the HIP runtime would prefer it over the command line's CUDA_VISIBLE_DEVICES)
+    assert "HIP_VISIBLE_DEVICES" not in M.sidecar_child_env()
+    # CUDA_VISIBLE_DEVICES in the parent: replaced by the command line's own -> the parent's i-th entry
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "2,3")
+    assert [M.sidecar_layout("out", r, 2, r, 1)[1] for r in range(2)] == [2, 3]
+    # ROCR_VISIBLE_DEVICES only: HIP / CUDA ordinals index the filtered list -> the rank-local index
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4,5,6,7")
+    assert [M.sidecar_layout("out", r, 4, r, 1)[1] for r in range(4)] == [0, 1, 2, 3]
+    assert M.sidecar_child_env().get("ROCR_VISIBLE_DEVICES") == "4,5,6,7"
 
 
 def test_gather_without_a_process_group_is_an_error_when_there_are_other_ranks():

@@ -1264,3 +1264,19 @@ def test_q_cross_attention_rejects_what_it_does_not_carry(ops):
     assert lib.tmix_gemm_q_cross_attn(C_.byref(d), *ops.q_cross_attn_args(k[:, :, :256], vt[:, :256], out[:, :256], 128, 0.125), None) == L.ESHAPE
     d = ops.make_gemm_desc(a, w, None)
     assert lib.tmix_gemm_q_cross_attn(C_.byref(d), *ops.q_cross_attn_args(k, vt, out, 96, 0.125), None) == L.ESHAPE     # rows_per_image % 64
+
+
+def test_long_row_quantiser_fallback_uses_the_kernels_scale_arithmetic(ops):
+    """rows longer than 8192 (conv weight rows of 9 * 1280) are quantised in torch; the E8M0 scale must be e8m0_for_amax's, bit for bit -- also where
+    amax is exactly 7 * 2^n, the boundary on which ceil(log2(amax / 448)) in double and the kernel's fp32 product can disagree."""
+    n = 40
+    amax = torch.tensor([7.0 * 2.0 ** (k - 20) for k in range(n)] + [448.0, 449.0, 447.0, 1.0, 3.0e-5, 0.0])
+    R = amax.numel()
+    short = torch.zeros(R, 8192)
+    short[:, 5] = amax
+    short[:, 77] = -amax * 0.5
+    long_ = torch.cat([short, torch.zeros(R, 64)], dim=1)                 # the same rows with 64 zero columns behind them: the torch path
+    q1, s1 = ops.quantize_fp8_rows(short.to(BF).cuda())
+    q2, s2 = ops.quantize_fp8_rows(long_.to(BF).cuda())
+    assert torch.equal(s1, s2)
+    assert torch.equal(q1, q2[:, :8192])

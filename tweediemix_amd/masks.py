@@ -87,14 +87,27 @@ def sidecar_layout(output_path, rank: int, world: int, local_gpu: int, seg_gpu: 
     if world <= 1:
         return output_path, seg_gpu
     gpu = local_gpu if 0 <= seg_gpu < world else seg_gpu
-    # the side-car's command line sets CUDA_VISIBLE_DEVICES itself, in PHYSICAL ids: when the parent already restricts the visible devices,
-    # rank-local index i is the i-th entry of the parent's list, not GPU i
-    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    # the side-car's command line sets CUDA_VISIBLE_DEVICES itself (fusion_sampling.py:458), and the child inherits the parent's environment:
+    #   * parent restricted by CUDA_VISIBLE_DEVICES: the child's own value replaces it -> the i-th entry of the parent's list;
+    #   * parent restricted by HIP_VISIBLE_DEVICES: the HIP runtime prefers that variable, so a child that inherits it would ignore its own
+    #     CUDA_VISIBLE_DEVICES and every side-car would land on the first visible GPU -> the i-th entry of the HIP list, and
+    #     SidecarMaskProvider drops HIP_VISIBLE_DEVICES from the child's environment (sidecar_child_env);
+    #   * parent restricted by ROCR_VISIBLE_DEVICES only: HIP / CUDA ordinals index the already filtered list -> the rank-local index as is.
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
     if vis and gpu == local_gpu:
         ids = [v.strip() for v in vis.split(",") if v.strip()]
         if 0 <= local_gpu < len(ids) and ids[local_gpu].lstrip("-").isdigit():
             gpu = int(ids[local_gpu])
     return os.path.join(output_path, f"rank{rank}"), gpu
+
+
+def sidecar_child_env():
+    """environment of the side-car process: the parent's without HIP_VISIBLE_DEVICES (see sidecar_layout: the command line's own
+    CUDA_VISIBLE_DEVICES must be what selects the GPU; ROCR_VISIBLE_DEVICES, which filters below both, stays)"""
+    import os
+    env = dict(os.environ)
+    env.pop("HIP_VISIBLE_DEVICES", None)
+    return env
 
 
 class SidecarMaskProvider:
@@ -121,7 +134,8 @@ class SidecarMaskProvider:
         Image.fromarray(arr).save(path)
         cmd = self.cmd_template.format(input_path=path, text_condition=self.seg_concepts, output_path=self.output_path,
                                        seg_gpu=self.seg_gpu)
-        os.system(cmd)                                                           # return code ignored, like the reference
+        import subprocess
+        subprocess.call(cmd, shell=True, env=sidecar_child_env())                # (os.system with a cleaned environment; return code ignored, like the reference)
         paths = [os.path.join(self.output_path, sp + ".jpg") for sp in self.seg_concepts.split("+")]
         s = self.sampler
         return build_masks(paths, s.h, s.w, s.device)

@@ -216,7 +216,10 @@ def quantize_fp8_rows(x, q=None, scale=None):
     if K > 8192:                       # rows longer than the kernel keeps in registers (conv weight rows: 9 * Cin): the same arithmetic in torch, once per checkpoint
         xf = x.float()
         amax = xf.abs().amax(dim=-1)
-        e = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)).float(), torch.zeros_like(amax)).clamp(-127, 127)
+        # e8m0_for_amax (csrc/common.h), bit for bit: the fp32 product amax * fl(1/448), its exponent, + 1 when the mantissa is not zero
+        bits = (amax.float() * torch.tensor(1.0 / 448.0, dtype=torch.float32, device=amax.device)).view(torch.int32)
+        e = (((bits >> 23) & 0xff) - 127 + ((bits & 0x7fffff) != 0).to(torch.int32)).clamp(-127, 127)
+        e = torch.where(amax > 0, e, torch.zeros_like(e)).float()
         qt = (xf * torch.exp2(-e).unsqueeze(-1)).to(torch.float8_e4m3fn).view(torch.uint8)
         st = (e + 127).to(torch.uint8)
         if q is not None:
