@@ -698,7 +698,7 @@ def main(argv=None):
             "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<..,CONV=0> (tmix_gemm_bf16)" if g is prof.get("gemm") else "gemm_conv_kernel<..,PH=2|3> (tmix_gemm_fp8)",
                          "achieved": g["tflops"], "peak": peak_tf, "unit": "TFLOP/s", "frac": g["tflops"] / peak_tf,
                          "traffic": pmc[0], "pmc": pmc[1], "algorithmic_bytes_per_launch": alg,
-                         "how": "achieved = sum(2MNK of the step's GEMM launches) / sum(their durations), each launch timed on the device clock "
+                         "how": "achieved = sum(2MNK of the step's GEMM launches, plus the 4*M*77*N attention flops of the one-launch attn2 -- tmix_gemm_q_cross_attn -- which that launch performs) / sum(their durations), each launch timed on the device clock "
                                 "INSIDE the captured step while the graph replays (concurrent chains included, so the sum can exceed the wall time)",
                          "launches_per_step": g["launches"], "avg_launch_us": g["avg_launch_us"], "flops_per_step": g["flops"],
                          "launches_per_step_all_classes": prof["launches_total"], "kernel_boundaries_ms": prof["boundaries_ms"],
