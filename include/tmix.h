@@ -122,7 +122,9 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_256x320_PH = 22 /* 256x320 with the phase-offset mainloop (eight waves of 64x160): bf16 GEMM, no transposed region */,
        TMIX_TILE_128x160_W22 = 23 /* 128x160 over 2 x 2 math waves of 64x80 (16x16x32 MFMA) + four loader waves: 72 KB instead of 96 KB of LDS fragment reads per K-tile;
                                       plain staged bf16 epilogue (bias, folded LayerNorm, residual, row statistics) -- other launches run as tiling 21 */,
-       TMIX_TILE_COUNT = 23 };
+       TMIX_TILE_256x320_P = 24 /* tiling 14 (256x320, eight waves) on PERSISTENT workgroups, one per CU: the next tile's first K-tile is requested under the current tile's last one;
+                                    the staged GEGLU epilogue on whole tiles (M %% 256 == 0, N %% 320 == 0), shared weights -- other launches run as tiling 14; same bits as 14 */,
+       TMIX_TILE_COUNT = 24 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

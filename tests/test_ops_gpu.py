@@ -209,7 +209,7 @@ def test_gemm_epilogues(ops, cfg):
     close(out, ref)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24])
 def test_gemm_geglu(ops, cfg):
     M, C = 200, 128
     a = rnd(M, C, seed=8)
@@ -1280,3 +1280,31 @@ def test_long_row_quantiser_fallback_uses_the_kernels_scale_arithmetic(ops):
     q2, s2 = ops.quantize_fp8_rows(long_.to(BF).cuda())
     assert torch.equal(s1, s2)
     assert torch.equal(q1, q2[:, :8192])
+
+
+# --------------------------------------------------------------------------- tiling 24 (gemm_ff1p.hip): 256 x 320 on persistent workgroups
+@pytest.mark.parametrize("M,N,K,ln", [(4096, 10240, 1280, True), (16384, 5120, 640, True), (2048, 10240, 1280, True), (256, 320, 128, False), (768, 960, 192, True), (512, 20480, 64 * 3, False)])
+def test_gemm_persistent_geglu_equals_tiling_14_bit_for_bit(ops, M, N, K, ln):
+    """the FF up-projection on persistent workgroups (one per CU walking 1, 2, 4 ... tiles: 512 / 1024 / 256 tiles at the SDXL shapes, and grids smaller
+    than the chip): same tile, same MFMA order, same epilogue arithmetic as tiling 14 -> identical bits; and both against the fp32 reference."""
+    from tweediemix_amd.weights import fold_layernorm, interleave_geglu
+    h = rnd(M, K, seed=601) * 1.3 + 0.4
+    w = rnd(N, K, seed=602, scale=K ** -0.5)
+    b = rnd(N, seed=603, dtype=torch.float32)
+    kw = {}
+    if ln:
+        gamma, beta = rnd(K, seed=604, dtype=torch.float32) * 0.2 + 1, rnd(K, seed=605, dtype=torch.float32) * 0.3
+        wp, cs, t = fold_layernorm(w, gamma, beta, b)
+        wi = interleave_geglu(wp, None)[0]
+        csi, ti = interleave_geglu(cs[:, None], t)
+        hf = h.float()
+        stats = torch.stack([hf.sum(-1), (hf ** 2).sum(-1)], -1).view(1, M, 2).contiguous()
+        kw = dict(ln_stats=stats, ln_colsum=csi[:, 0].contiguous())
+        z = F.layer_norm(hf, (K,), gamma, beta, 1e-5) @ w.float().T + b
+    else:
+        wi, ti = interleave_geglu(w, b)
+        z = h.float() @ w.float().T + b
+    y24 = ops.gemm(h, wi, bias=ti, geglu=True, tile_cfg=24, **kw)
+    y14 = ops.gemm(h, wi, bias=ti, geglu=True, tile_cfg=14, **kw)
+    assert torch.equal(y24, y14)
+    close(y24, z[:, :N // 2] * F.gelu(z[:, N // 2:]), rtol=2 ** -6, atol_frac=4e-3)
