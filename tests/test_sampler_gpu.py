@@ -173,10 +173,15 @@ def test_end_to_end_vs_oracle_sampler(kind, graphs, streams):
         assert r <= (6e-2 if int(t) == tw.start_t else 2e-2), (t, r)
 
 
-def test_two_seeds_co_batched_equal_independent_runs():
+def test_two_seeds_co_batched_equal_independent_runs(monkeypatch):
     """n_seeds=2 shares every UNet launch between two trajectories; each must match its own single-seed run
-    (rows of different seeds never interact: attention is per batch row, norms are per sample)."""
+    (rows of different seeds never interact: attention is per batch row, norms are per sample).
+    Both plans are built with ONE tiling everywhere (TMIX_FORCE_TILE): the single-seed and the two-seed launches have different shape keys, the tuner
+    times them separately, and two tilings with different wave tiles add up a row's LayerNorm statistics in another lane order -- a one-ulp difference in
+    eps (tools/tile_equiv.py) that ten steps of a random-weight UNet blow up to 0.4: the test then failed in two of four full-suite runs of round 5 and
+    passed alone.  What it checks is seed independence, not the tuner."""
     need_gpu()
+    monkeypatch.setenv("TMIX_FORCE_TILE", "1")
     from tweediemix_amd import masks as M, sampler as S
     K, n, h, w = 3, 10, 16, 16
     for kind in ("custom", "lora"):
@@ -198,8 +203,10 @@ def test_two_seeds_co_batched_equal_independent_runs():
             return M.build_masks(imgs[i], h, w)
         tw2 = S.Tweediemix(cfg, W, te, ts, provider, concept_num=K, lora=(kind == "lora"), n_seeds=2)
         both = tw2.run_fusion(xT.clone()).cpu()
+        from tweediemix_amd import unet as U
         for i in range(2):
-            torch.testing.assert_close(both[i:i + 1], singles[i], rtol=1e-3, atol=1e-3)
+            d = (both[i:i + 1] - singles[i]).abs().max().item()
+            assert d <= 1e-3, (kind, i, d, {k: U.used_tilings(p) for k, p in tw2.plans.items()}, {k: U.used_tilings(p) for k, p in tw.plans.items()})
         assert tw2.plan("fusion").B == 8 and [c[1] for c in tw2.unet_calls][:1] == [4]
 
 
