@@ -223,6 +223,9 @@ __global__ void __launch_bounds__((Q_NW + Q_LW) * 64, 2) gemm_qattn_kernel(const
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int i = q >> 2, j = q & 3;
+#ifdef TMIX_QATTN_ABL4      // dev ablation (tools/build_variant.sh): the fifth math wave (the second one on its SIMD) issues no MFMAs in the K loop -- wrong results, the loop's
+            if (h < 4)               // time without the doubly-loaded SIMD
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[S][j], fa[S][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (q < 4) fa[1 - S][q] = *(const frag_ab*)(pa + q * 16 * 128);
