@@ -416,7 +416,8 @@ def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, s
 # every OTHER call the bench line times (images_per_s, trajectory_steps_per_s, single_image): the un-routed B = 4 `start` and `fusion_base` plans, the
 # B = 2 `plain` plan (33 of a LoRA image's 75 calls; the one-workgroup-per-CU 64x160 / 32x160 tilings), and the 4-seed co-batched forms of all four
 # (B = 16 / 8, `w_period` weight sets, their own table entries) that produce the line's images/s -- bf16 and fp8
-_CALL_CASES = [(ck, ns) for ck in ("fusion", "fusion_base", "start", "plain") for ns in (1, 4) if (ck, ns) != ("fusion", 1)]
+# (8 seeds: BASELINE config 4's one-GPU share -- 64 seeds over 8 GPUs -- and bench.py's default --traj-cobatch since round 5)
+_CALL_CASES = [(ck, ns) for ck in ("fusion", "fusion_base", "start", "plain") for ns in (1, 4, 8) if (ck, ns) != ("fusion", 1)]
 
 
 @pytest.mark.parametrize("fp8", [False, True])
