@@ -124,7 +124,8 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
                                       plain staged bf16 epilogue (bias, folded LayerNorm, residual, row statistics) -- other launches run as tiling 21 */,
        TMIX_TILE_256x320_P = 24 /* tiling 14 (256x320, eight waves) on PERSISTENT workgroups, one per CU: the next tile's first K-tile is requested under the current tile's last one;
                                     the staged GEGLU epilogue on whole tiles (M %% 256 == 0, N %% 320 == 0), shared weights -- other launches run as tiling 14; same bits as 14 */,
-       TMIX_TILE_COUNT = 24 };
+       TMIX_TILE_128x160_W22_PF = 25 /* tiling 23 with three DMA loader waves and one L2 PREFETCHER wave that touches the tile's A / W lines eight K-tiles ahead of the LDS ring */,
+       TMIX_TILE_COUNT = 25 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

@@ -1177,6 +1177,20 @@ def test_gemm_w22_bias_residual_statistics_and_folded_layernorm(ops, M, N, K, ba
     close(y, F.layer_norm(hf, (N,), gamma, beta, 1e-5) @ w2.float().T + b2, rtol=2 ** -6, atol_frac=4e-3)
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(4096, 1280, 5120, 1), (1024, 1280, 1280, 4), (300, 640, 2560, 1), (129, 320, 192, 3), (128, 160, 64, 1)])
+def test_gemm_w22_with_l2_prefetcher_wave_equals_tiling_23_bit_for_bit(ops, M, N, K, batch):
+    """tiling 25 = tiling 23's math waves behind three DMA loaders and one prefetcher wave: the same bits, whatever the K depth (1 to 80 K-tiles)"""
+    shp = (batch, M) if batch > 1 else (M,)
+    a = rnd(*shp, K, seed=421)
+    w = rnd(*((batch,) if batch > 1 else ()), N, K, seed=422, scale=K ** -0.5)
+    bias = rnd(N, seed=423, dtype=torch.float32)
+    res = rnd(*shp, N, seed=424)
+    s23 = torch.zeros(N // 160, batch * M, 2, device="cuda"); s25 = torch.zeros_like(s23)
+    y23 = ops.gemm(a, w, bias=bias, residual=res, row_stats_out=s23, tile_cfg=23)
+    y25 = ops.gemm(a, w, bias=bias, residual=res, row_stats_out=s25, tile_cfg=25)
+    assert torch.equal(y23, y25) and torch.equal(s23, s25)
+
+
 def test_gemm_w22_falls_back_for_launches_it_does_not_carry(ops):
     """GEGLU, a transposed region, an activation, a row-group bias or a width that is not a multiple of 160 run as tiling 21 / 12: same results as asking for those"""
     from tweediemix_amd.weights import interleave_geglu

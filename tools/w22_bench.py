@@ -33,7 +33,7 @@ for name, b, M, N, K in shapes:
     res = torch.randn(b, M, N, device="cuda").to(BF)
     out = torch.empty(b, M, N, device="cuda", dtype=BF)
     row = []
-    for cfg in (12, 20, 21, 23):
+    for cfg in (12, 20, 21, 23, 25):
         parts = ops.stats_parts(N, cfg)
         stats = torch.zeros(parts, b * M, 2, device="cuda")
         d = ops.make_gemm_desc(a, w, out, bias=bias, residual=res, row_stats_out=stats, tile_cfg=cfg)

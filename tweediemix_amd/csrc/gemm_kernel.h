@@ -1580,7 +1580,8 @@ struct TileCfg { int bm, bn; };
 // K-tile hand-over -- 79 % of the MFMA rate with the LDS-DMA ablated -- where this one keeps one wave of every SIMD in its MFMA segment
 // 23 = 128x160 over 2 x 2 math waves of 64x80 on v_mfma_f32_16x16x32_bf16 + four loader waves (its own kernel: gemm_w22.hip)
 // 24 = 256x320 (tiling 14's tile and arithmetic) on PERSISTENT workgroups: one per CU walks its tiles, the next tile's first K-tile requested under the last one (gemm_ff1p.hip)
-constexpr int NUM_CFG = 24;
+// 25 = tiling 23 with the fourth loader wave as an L2 PREFETCHER (touches the tile's operand lines eight K-tiles ahead of the ring)
+constexpr int NUM_CFG = 25;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -1633,7 +1634,7 @@ int launch_group3(int cfg, int conv, int f8, Params& p, int batch, hipStream_t s
 int launch_group4(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);
 int launch_group5(int cfg, int conv, int f8, Params& p, int batch, hipStream_t st);      // fp8 in the lock-step loops (f8 = 3: per-row A scales, 4: MX blocks)
 bool w22_eligible(const Params& p, int conv, int f8);                                   // gemm_w22.hip (tiling 23)
-int launch_w22(Params& p, int batch, hipStream_t st);
+int launch_w22(Params& p, int batch, hipStream_t st, int l2_prefetcher = 0);            // (1: tiling 25, three DMA loaders + an L2 prefetcher wave)
 bool ff1p_eligible(const Params& p, int conv, int f8, int batch);                        // gemm_ff1p.hip (tiling 24)
 int launch_ff1p(Params& p, hipStream_t st);
 // gemm_qattn.hip: attn2.to_q + the cross-attention behind it in one launch (tmix_gemm_q_cross_attn)

@@ -29,6 +29,12 @@ constexpr int W_PASSES = (32 * W_CG) / 64;                             // read-b
 static_assert((W_BM / 8) % W_LW == 0 && (W_BN / 8) % W_LW == 0 && (32 * W_CG) % 64 == 0, "geometry");
 static_assert(W_NW * W_PATCH + 2 * W_BM * W_CG * 8 <= W_RING, "epilogue patches + statistics exchange fit in the staging ring");
 
+// PFW = 1 (tiling 25): the fourth loader wave issues no LDS-DMA -- it walks W_PD K-tiles AHEAD of the ring and touches this tile's A and W lines (one dword per 128-byte
+// line), so that they are in this XCD's L2 when the three DMA loaders ask for them: the ring holds 2 - 3 K-tiles (~1.5 us of lookahead), a line that comes cold through the
+// fabric takes longer than that, and nothing in the LDS budget can deepen the ring.  Its own wave, because vmcnt retires in order: a slow touch in a DMA loader's queue would hold
+// back the hand-over of every K-tile behind it.
+constexpr int W_PD = 8;
+template <int PFW>
 __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifndef TMIX_NO_KERNARG_TOUCH
@@ -78,29 +84,63 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
         // LDS position q of row r holds source chunk q ^ ((r >> 1) & 7) -- the permutation rides in the lane's SOURCE address
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, p.bytesA, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, p.bytesW, 0x00020000);
-        const int s = w - W_NW, par = s & 1, lrow = lane >> 3;
-        const unsigned sw = (unsigned)(((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) * 16);        // bytes
-        const unsigned woff = (unsigned)(n0 + par * 8 + lrow) * (unsigned)p.ldw * 2u + sw, wmax = (unsigned)(p.N - 1) * (unsigned)p.ldw * 2u + sw;
-        const unsigned aoff = (unsigned)(m0 + par * 8 + lrow) * (unsigned)p.lda * 2u + sw, amax = (unsigned)(p.M - 1) * (unsigned)p.lda * 2u + sw;
+        const int s = w - W_NW, lrow = lane >> 3;
+        constexpr int DL = W_LW - PFW, IA = W_BM / 8, L = (W_BM / 8 + W_BN / 8) / DL;        // DMA loaders; A instructions of a K-tile; instructions per loader
+        static_assert((W_BM / 8 + W_BN / 8) % DL == 0 && (W_NS - 2) * L <= 63, "loader geometry");
+        if (PFW && s == DL) {
+            // ---- L2 prefetcher wave: line slot i * 64 + lane = A row (< 128) or W row of the tile
+            constexpr int NLI = (W_BM + W_BN + 63) / 64;
+            const char* lp[NLI];
+#pragma unroll
+            for (int i = 0; i < NLI; ++i) {
+                const int line = i * 64 + lane;
+                lp[i] = line < W_BM ? (const char*)Ab + (int64_t)min(m0 + line, p.M - 1) * p.lda * 2
+                      : line < W_BM + W_BN ? (const char*)Wb + (int64_t)min(n0 + line - W_BM, p.N - 1) * p.ldw * 2 : nullptr;
+            }
+            unsigned sink = 0;
+            auto touch = [&](int kp) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < NLI; ++i)
+                    if (lp[i]) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(lp[i] + (int64_t)kp * (BK * 2)) : "memory");
+            };
+            for (int kp = W_NS - 1; kp <= W_PD && kp < nk; ++kp) touch(kp);
+            __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + W_PD + 1 < nk) touch(kt + W_PD + 1);
+                __builtin_amdgcn_s_barrier();
+            }
+            wait_vmcnt<0>();
+            asm volatile("" :: "v"(sink));
+#pragma unroll
+            for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));
+            if (p.stats_out) __syncthreads();
+            return;
+        }
+        // DMA loaders: instruction g = DL r + s of a K-tile: g < 16 -> A rows 8 g .., else W rows 8 (g - 16) ..; the swizzle depends on the instruction's parity only
+        const unsigned sw0 = (unsigned)(((lane & 7) ^ ((lane >> 4) & 7)) * 16), sw1 = (unsigned)(((lane & 7) ^ ((4 + (lane >> 4)) & 7)) * 16);
+        const unsigned aoff0 = (unsigned)(m0 + lrow) * (unsigned)p.lda * 2u + sw0, dA = 16u * (unsigned)p.lda + sw1 - sw0;
+        const unsigned woff0 = (unsigned)(n0 + lrow) * (unsigned)p.ldw * 2u + sw0, dW = 16u * (unsigned)p.ldw + sw1 - sw0;
+        const unsigned amax0 = (unsigned)(p.M - 1) * (unsigned)p.lda * 2u + sw0, wmax0 = (unsigned)(p.N - 1) * (unsigned)p.ldw * 2u + sw0, dS = sw1 - sw0;
         auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
             char* sA = smem + buf * W_STAGE;
             char* sW = sA + W_ATILE;
 #pragma unroll
-            for (int r = 0; r < W_RA; ++r) {
-                const int idx = r * W_LW + s;
-                blds16(rsA, min(aoff + (unsigned)(idx >> 1) * (unsigned)(32 * p.lda), amax), (unsigned)kt * (BK * 2), sA + idx * 1024);
-            }
-#pragma unroll
-            for (int r = 0; r < W_RB; ++r) {
-                const int idx = r * W_LW + s;
-                blds16(rsW, min(woff + (unsigned)(idx >> 1) * (unsigned)(32 * p.ldw), wmax), (unsigned)kt * (BK * 2), sW + idx * 1024);
+            for (int r = 0; r < L; ++r) {
+                const int g = r * DL + s;              // wave-uniform
+                if (g < IA) {
+                    const unsigned odd = 0u - (unsigned)(g & 1);
+                    blds16(rsA, min(aoff0 + (dA & odd) + (unsigned)(g >> 1) * (unsigned)(32 * p.lda), amax0 + (dS & odd)), (unsigned)kt * (BK * 2), sA + g * 1024);
+                } else {
+                    const int idx = g - IA; const unsigned odd = 0u - (unsigned)(idx & 1);
+                    blds16(rsW, min(woff0 + (dW & odd) + (unsigned)(idx >> 1) * (unsigned)(32 * p.ldw), wmax0 + (dS & odd)), (unsigned)kt * (BK * 2), sW + idx * 1024);
+                }
             }
         };
         constexpr int PRE = 2;
 #pragma unroll
         for (int t = 0; t < PRE; ++t)
             if (t < nk) stage(t, t);
-        if (nk >= PRE) wait_vmcnt<(PRE - 1) * W_L>(); else wait_vmcnt<0>();
+        if (nk >= PRE) wait_vmcnt<(PRE - 1) * L>(); else wait_vmcnt<0>();
 #pragma unroll
         for (int u = 0; u < PFU; ++u) asm volatile("" :: "v"(pf_keep[u]));
         __builtin_amdgcn_s_barrier();
@@ -111,7 +151,7 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + W_NS - 1 < nk;
             if (more) stage(nxt, kt + W_NS - 1);      // its ring slot was released by the barrier that ended iteration kt - 1
-            if (more) wait_vmcnt<(W_NS - 2) * W_L>(); else wait_vmcnt<0>();
+            if (more) wait_vmcnt<(W_NS - 2) * L>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             nxt = (nxt + 1 == W_NS) ? 0 : nxt + 1;
         }
@@ -329,12 +369,12 @@ bool w22_eligible(const Params& p, int conv, int f8) {
            && (p.N % W_BN) == 0 && (!p.R || (p.ldr % 8) == 0);
 }
 
-int launch_w22(Params& p, int batch, hipStream_t st) {
+template <int PFW> static int launch_w22_t(Params& p, int batch, hipStream_t st) {
     constexpr int SMEM = W_RING + (W_BM + W_BN) * 16 + W_BM * 4 + W_BN * 4;
     static_assert(SMEM <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_w22_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_w22_kernel<PFW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) TMIX_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -345,9 +385,11 @@ int launch_w22(Params& p, int batch, hipStream_t st) {
     tmix_prefetch_take(&p.pf, &p.pf_bytes);
     { const long long nthr = (long long)grid.x * grid.y * W_LW * 64, lines = (p.pf_bytes + 127) >> 7;
       p.pf_per = p.pf ? (int)((lines + nthr - 1) / nthr) : 0; }
-    gemm_w22_kernel<<<grid, (W_NW + W_LW) * 64, SMEM, st>>>(p);
+    gemm_w22_kernel<PFW><<<grid, (W_NW + W_LW) * 64, SMEM, st>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }
+
+int launch_w22(Params& p, int batch, hipStream_t st, int l2_prefetcher) { return l2_prefetcher ? launch_w22_t<1>(p, batch, st) : launch_w22_t<0>(p, batch, st); }
 
 }  // namespace tmix_gemm

@@ -495,7 +495,7 @@ class UNetPlan:
             st = torch.cuda.current_stream().cuda_stream
             best_t = {}                                             # (key, cfg) -> min over reps of the summed launch times
             cands = list(L.TILE_CANDIDATES)                         # (16 / 17 and the loader-wave tilings 19 / 20 exist for the plain GEMM only)
-            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 21: 12, 22: 14, 23: 12, 24: 14}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
+            conv_alias = {16: 4, 17: 2, 18: 12, 19: 12, 21: 12, 22: 14, 23: 12, 24: 14, 25: 12}    # what gemm_conv.hip runs for a convolution: timed once, under the live id
             for _rep in range(reps):
                 for cfg in cands:
                     for _i, kind, d in tun:
@@ -1180,7 +1180,7 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
         cur = members[k][0][2].tile_cfg
         best, best_t = cur, base
         for cfg in (cands or L.TILE_CANDIDATES):
-            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 18, 19, 21, 22, 23, 24)):
+            if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 18, 19, 21, 22, 23, 24, 25)):
                 continue
             for p, _kind, d in members[k]:
                 d.tile_cfg = cfg
