@@ -21,7 +21,7 @@ constexpr int W_BM = 128, W_BN = 160, W_NS = 4, W_LW = 4, W_NW = 4;
 constexpr int W_TM = 64, W_TN = 80, W_FM = 4, W_FN = 5;               // wave tile and its 16 x 16 fragments
 constexpr int W_ATILE = W_BM * 128, W_BTILE = W_BN * 128, W_STAGE = W_ATILE + W_BTILE;
 constexpr int W_RING = W_NS * W_STAGE;
-constexpr int W_RA = (W_BM / 8) / W_LW, W_RB = (W_BN / 8) / W_LW, W_L = W_RA + W_RB;     // LDS-DMA instructions per loader and K-tile: 4 + 5
+// (LDS-DMA instructions per K-tile: 16 for A + 20 for W, dealt to the 4 -- or 3, tiling 25 -- DMA loader waves)
 constexpr int W_SR = W_TN * 4 + 16;                                    // bytes per row of a wave's staging patch (80 fp32 columns + pad)
 constexpr int W_PATCH = 32 * W_SR;                                     // 32-row half of a wave tile
 constexpr int W_CG = W_TN / 8;                                         // 8-column groups per row of a wave tile (one 16-byte store each)
