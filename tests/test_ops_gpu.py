@@ -1322,3 +1322,57 @@ def test_gemm_persistent_geglu_equals_tiling_14_bit_for_bit(ops, M, N, K, ln):
     y14 = ops.gemm(h, wi, bias=ti, geglu=True, tile_cfg=14, **kw)
     assert torch.equal(y24, y14)
     close(y24, z[:, :N // 2] * F.gelu(z[:, N // 2:]), rtol=2 ** -6, atol_frac=4e-3)
+
+
+# --------------------------------------------------------------------------- the fp16 rounding points, by the device's own torch
+@pytest.mark.parametrize("mode", ["fusion", "plain", "resample", "last"])
+@pytest.mark.parametrize("K,h,w", [(3, 16, 16), (3, 128, 128), (2, 8, 12)])
+def test_fp16_step_equals_the_references_statements_evaluated_by_torch_on_the_device(ops, mode, K, h, w):
+    """the fp16-eps mode's bit-level claim rested on the oracle's CPU_SCALAR_TENSOR_SEMANTICS switch ("an argument, not a vector").  Here the vector is made on
+    the spot: the statements of fusion_sampling.py:376-385 (fusion), :424-430 (plain), :391-402 (first half of a resampling repeat) and :471-472 (t == 1) are evaluated by torch ON THE
+    DEVICE -- fp16 noise_pred (what the UNet returns under autocast, :492), fp32 x, python-float guidance scale, `at` / `at_next` 0-dim fp32 CPU tensors exactly as
+    `self.scheduler.alphas_cumprod[t]` hands them over (:305-307) -- i.e. with the scalar-tensor promotion and rounding the reference really executes on a GPU, and the fused kernel's
+    fp16 mode must reproduce the result (to the reciprocal-vs-division ulp, see below)."""
+    from tweediemix_amd import lib as L
+    g = torch.Generator().manual_seed(K * 1000 + h)
+    x = torch.randn(1, 4, h, w, generator=g).cuda()
+    noise_pred = torch.randn(K + 1, 4, h, w, generator=g).half().cuda()
+    masks = (torch.rand(K, 1, h, w, generator=g) > 0.6).float().cuda()
+    at, at_next = torch.tensor(0.2345), torch.tensor(0.3456)             # 0-dim fp32 CPU tensors (alphas_cumprod lives on the CPU)
+    gs = 0.8
+    noise_pred_uncond = noise_pred[:1]
+    if mode in ("fusion", "last"):
+        denoised_tweedie = 0
+        for cc in range(K):
+            noise_pred_cond = noise_pred[(1 + cc):(2 + cc)]
+            noise_pred_concept = noise_pred_uncond + gs * (noise_pred_cond - noise_pred_uncond)
+            denoised_tweedie += masks[cc].unsqueeze(0) * ((x - (1 - at).sqrt() * noise_pred_concept) / at.sqrt())
+        m = L.STEP_FUSION
+    elif mode == "plain":
+        noise_pred_cond = noise_pred[1:2]
+        npred = noise_pred_uncond + gs * (noise_pred_cond - noise_pred_uncond)
+        denoised_tweedie = (x - (1 - at).sqrt() * npred) / at.sqrt()
+        m = L.STEP_PLAIN
+    else:
+        noise_pred_mult = noise_pred[1:2]
+        noise_pred_mult = noise_pred_uncond + gs * (noise_pred_mult - noise_pred_uncond)
+        denoised_tweedie_mult = (x - (1 - at).sqrt() * noise_pred_mult) / at.sqrt()
+        denoised_tweedie = (K - 1) * denoised_tweedie_mult
+        for cc in range(K - 1):
+            noise_pred_single = noise_pred_uncond + gs * (noise_pred[2 + cc:3 + cc] - noise_pred_uncond)
+            denoised_tweedie_single = (x - (1 - at).sqrt() * noise_pred_single) / at.sqrt()
+            denoised_tweedie -= denoised_tweedie_single
+        m = L.STEP_RESAMPLE
+    denoised_latent = at_next.sqrt() * denoised_tweedie + (1 - at_next).sqrt() * noise_pred_uncond
+    if mode == "last":
+        denoised_latent = denoised_tweedie
+    assert denoised_latent.dtype == torch.float32 and denoised_tweedie.dtype == torch.float32
+    x0 = torch.empty_like(x)
+    out = ops.fused_tweedie_step(x, noise_pred, masks, m, K, gs, np.float32(at.item()), np.float32(at_next.item()), mode == "last", out_x0=x0)
+    torch.cuda.synchronize()
+    # agreement to a few fp32 ulps, not bit for bit: torch's GPU kernel divides by a CPU-scalar tensor as a multiplication by its reciprocal (the fused kernel and the numpy
+    # oracle -- pinned to fixtures the reference's code produced on the CPU -- divide), a 1e-7 effect; a wrong fp16 rounding point would show at 1e-3 of an element
+    tol = 4e-6 * denoised_latent.abs().max().item()
+    assert (out - denoised_latent).abs().max().item() <= tol, (out - denoised_latent).abs().max().item()
+    if mode != "resample":
+        assert (x0 - denoised_tweedie).abs().max().item() <= 4e-6 * denoised_tweedie.abs().max().item()
