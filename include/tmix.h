@@ -279,6 +279,19 @@ int tmix_attn_fwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, in
 int tmix_attn_fwd_f8(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
                      const void* Vt, int64_t ldvt, int64_t strideVt, void* O8, int64_t ldo8, void* scales, int64_t ldScale,
                      int B, int H, int Sq, int Skv, float scale, void* stream);
+/* The same two launches with a caller-owned workspace for the KEY-SPLIT TAIL.  B * H * ceil(Sq / 128) work items run on 512 workgroup slots; where a last,
+ * partly filled round remains (the reference's attn1 at SDXL 1024^2, utils_lora.py:101-111 at B = 4: 640 items at S = 1024, 1280 at S = 4096) its items
+ * are cut into 2 or 4 key ranges, one workgroup each, whose partial (o, maximum, row sum) meet in the workspace; the item's last arriver adds them in range
+ * order (a fixed order: results do not depend on arrival) and stores.  tmix_attn_split_ws_bytes: bytes that enable the split for a shape (0: the shape does
+ * not split; then, and with ws = NULL, the calls are exactly the two above).  The workspace is zero-filled ONCE by the caller (its first 4 KiB are ticket
+ * counters every launch leaves at zero) and belongs to one stream at a time.  Results differ from the unsplit launch by fp32 rounding of the merge only. */
+int64_t tmix_attn_split_ws_bytes(int B, int H, int Sq, int Skv);
+int tmix_attn_fwd_ws(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                     const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                     int B, int H, int Sq, int Skv, float scale, void* ws, int64_t ws_bytes, void* stream);
+int tmix_attn_fwd_f8_ws(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                        const void* Vt, int64_t ldvt, int64_t strideVt, void* O8, int64_t ldo8, void* scales, int64_t ldScale,
+                        int B, int H, int Sq, int Skv, float scale, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisation / small ops (diffusers GroupNorm(32)+SiLU, LayerNorm, Timesteps, time MLPs).

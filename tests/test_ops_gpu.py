@@ -424,6 +424,75 @@ def test_attention_strided_qkv(ops):
     close(out, ref.transpose(1, 2).reshape(B, S, Cc), rtol=2 ** -6, atol_frac=4e-3)
 
 
+@pytest.mark.parametrize("B,H,S,parts", [(4, 20, 1024, 4), (4, 10, 4096, 2), (8, 20, 1024, 2), (1, 20, 4096, 4)])
+def test_attention_key_split_tail(ops, B, H, S, parts):
+    """tmix_attn_fwd_ws: the items of the partly filled last round (SDXL attn1 at 1024^2: 640 items at S = 1024, 1280 at S = 4096 on 512 slots) are cut
+    into key ranges that meet in the workspace.  Against the fp32 reference, against the unsplit launch (fp32 merge rounding only: a bf16 ulp), bit-stable
+    from launch to launch (the merge order is the range order, not the arrival order), ticket counters back at zero; rows with one dominant late key
+    (the ranges' maxima differ by far) and the e4m3 output form included."""
+    from tweediemix_amd import lib as L
+    Cc = H * 64
+    l = L.load()
+    need = l.tmix_attn_split_ws_bytes(B, H, S, S)
+    items, slots = B * H * (S // 128), 512
+    assert need == 4096 + (items % slots) * parts * 4 * 9 * 64 * 16
+    qk = rnd(B, S, 2 * Cc, seed=48)
+    v = rnd(B, S, Cc, seed=49)
+    hq, hk = (H - 1) * 64, Cc + (H - 1) * 64                  # the last head of the last batch row is in the split tail: a loud key in its LAST
+    qk[B - 1, S - 5, hk:hk + 64] = qk[B - 1, 7, hq:hq + 64] * 4.0       # range for query 7, one in the first range for query 900
+    qk[B - 1, 3, hk:hk + 64] = qk[B - 1, 900, hq:hq + 64] * 4.0
+    vt = v.transpose(1, 2).contiguous()
+    q, k = qk[:, :, :Cc], qk[:, :, Cc:]
+    base = ops.attention(q, k, vt, H, S, 0.125)
+    ws = ops.attention_split_ws(B, H, S, S, "cuda")
+    assert ws is not None and ws.numel() == need
+    out = ops.attention(q, k, vt, H, S, 0.125, ws=ws)
+    out2 = ops.attention(q, k, vt, H, S, 0.125, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+    n_full = items - items % slots                              # whole items are untouched by the split
+    rows_full = n_full // (S // 128) // H                       # batch rows made of whole items only
+    if rows_full:
+        assert torch.equal(out[:rows_full], base[:rows_full])
+    assert not torch.equal(out, base)                           # ... and the tail really took the other path
+    d = (out.float() - base.float()).abs()
+    assert float(d.max()) <= 2 ** -7 * float(base.float().abs().max())
+
+    def heads(t):
+        return t.float().reshape(t.shape[0], -1, H, 64).transpose(1, 2)
+    for b0 in range(0, B, 2):                                   # (fp32 scores of two batch rows at a time)
+        sl = slice(b0, min(B, b0 + 2))
+        ref = F.scaled_dot_product_attention(heads(q[sl]), heads(k[sl]), heads(v[sl]), scale=0.125)
+        close(out[sl], ref.transpose(1, 2).reshape(-1, S, Cc), rtol=2 ** -6, atol_frac=4e-3)
+    # e4m3 output: the bytes a quantiser makes of the bf16 tensor of the SAME (split) launch
+    cp = ops.F8Copy(B * S, Cc, "cuda")
+    ops.attention(q, k, vt, H, S, 0.125, f8_out=cp, ws=ws)
+    torch.cuda.synchronize()
+    qq, ss, _deq = _mx_quantize(out.float().view(B * S, Cc))
+    assert torch.equal(cp.scales, ss)
+    same = (cp.q == qq) | (((cp.q & 0x7f) == 0) & ((qq & 0x7f) == 0))
+    assert same.all(), int((~same).sum())
+
+
+def test_attention_key_split_applies_to_partly_filled_last_rounds_only(ops):
+    from tweediemix_amd import lib as L
+    l = L.load()
+    for shape in [(2, 20, 1024, 1024), (16, 20, 1024, 1024), (4, 20, 1024, 77), (4, 20, 1024, 1000), (1, 1, 128, 128), (4, 20, 1024, 64)]:
+        assert l.tmix_attn_split_ws_bytes(*shape) == 0, shape
+        assert ops.attention_split_ws(*shape, "cuda") is None
+    # a workspace that is too small is refused, not overrun
+    B, H, S = 4, 20, 1024
+    qk, v = rnd(B, S, 2 * H * 64, seed=48), rnd(B, S, H * 64, seed=49)
+    small = torch.zeros(8192, device="cuda", dtype=torch.uint8)
+    with pytest.raises(RuntimeError):
+        ops.attention(qk[:, :, :H * 64], qk[:, :, H * 64:], v.transpose(1, 2).contiguous(), H, S, 0.125, ws=small)
+    # a shape that does not split ignores the workspace
+    o1 = ops.attention(qk[:2, :, :H * 64], qk[:2, :, H * 64:], v[:2].transpose(1, 2).contiguous(), H, S, 0.125, ws=small)
+    o0 = ops.attention(qk[:2, :, :H * 64], qk[:2, :, H * 64:], v[:2].transpose(1, 2).contiguous(), H, S, 0.125)
+    assert torch.equal(o0, o1)
+
+
 # --------------------------------------------------------------------------- norms / small ops
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (1, 100, 64, 0, False), (2, 64, 640, 320, True),
                                              (1, 1024, 1280, 1280, True), (4, 16, 32, 0, False)])

@@ -46,6 +46,9 @@ struct AttnParams {
     // tmix_attn_fwd_f8: the output leaves as e4m3 bytes [B*Sq][ldo8] with one E8M0 scale per (row, 32 columns) in the k-block-major form
     // [C/32][ldSc] -- the block-scaled A operand of the out-projection (tmix_gemm_fp8, TMIX_F8_A_BLOCK_SCALES); O is not written then
     unsigned char* O8; int64_t ldo8; unsigned char* Sc; int64_t ldSc;
+    // key-split tail (attn_fwd_pipe_kernel): the first n_full workgroups take whole (batch, head, query block) items, the items behind them are cut into
+    // 1 << lsplit key ranges of tpp tiles each (one workgroup per range); partial results meet in ws, the item's last arriver (ticket) merges and stores
+    int n_full, lsplit, tpp; float* ws; unsigned* tickets;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
@@ -99,6 +102,13 @@ __device__ __forceinline__ void store_row_f8(const AttnParams& p, int64_t row, i
     }
 }
 
+// 16-byte store / load at the device's coherence point (what an agent-scope atomic store / load does on gfx950, sc1, at four times the width): partial
+// results that workgroups on DIFFERENT XCDs (different L2s) exchange inside one launch.  The load is asynchronous: s_waitcnt vmcnt before the value is used.
+constexpr int SPLIT_MAX = 4;         // key ranges per item, at most
+constexpr int SPLIT_VEC = 9;         // f32x4 per lane of a key range's partial result: o[4][2] + (reference maxima, row sums)
+__device__ __forceinline__ void st_coherent(f32x4* dst, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld_coherent(const f32x4* src) { f32x4 v; asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(src) : "memory"); return v; }
+
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     bf16x2_t v = {(__bf16)a, (__bf16)b};
     return *(uint32_t*)&v;
@@ -128,13 +138,24 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
     unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
     if (prof_on) pt0 = prof_enter(p.prof, blockIdx.x == 0, p.prof_detail);
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // workgroups are dispatched in id order and dealt to the XCDs round robin: ids < n_full are whole items (a contiguous run per XCD: the query blocks of a
+    // head share its K / V in one L2); the ids behind them are the key ranges of the remaining items, all ranges of an item on ONE XCD
+    int bid, part = 0;
+    if ((int)blockIdx.x < p.n_full) bid = xcd_remap(blockIdx.x, p.n_full);
+    else {
+        const int j = (int)blockIdx.x - p.n_full, k = j >> 3, n_tail8 = ((int)gridDim.x - p.n_full) >> (3 + p.lsplit);
+        bid = p.n_full + (j & 7) * n_tail8 + (k >> p.lsplit);
+        part = k & ((1 << p.lsplit) - 1);
+    }
+    const bool split = (int)blockIdx.x >= p.n_full;
     const int bh = bid / p.nq, qt = bid - bh * p.nq;
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qt * QB + w * 32;
+    const int key0 = split ? part * p.tpp * KB : 0;              // this workgroup's key range [key0, key0 + skv)
+    const int skv = split ? p.tpp * KB : p.Skv;
     const bf16_t* Qb = p.Q + (int64_t)b * p.strideQ + h * 64;
-    const bf16_t* Kb = p.K + (int64_t)b * p.strideK + h * 64;
-    const bf16_t* Vb = p.Vt + (int64_t)b * p.strideVt + (int64_t)h * 64 * p.ldvt;
+    const bf16_t* Kb = p.K + (int64_t)b * p.strideK + h * 64 + (int64_t)key0 * p.ldk;
+    const bf16_t* Vb = p.Vt + (int64_t)b * p.strideVt + (int64_t)h * 64 * p.ldvt + key0;
 
     // ---- staging: per wave 2 rounds x (8 rows x 8 chunks) for K and for V^T, XOR-swizzled through the source address
     const int lrow = lane >> 3;
@@ -148,16 +169,17 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
         krow[r] = 32 * (f >> 1) + 8 * (i >> 2) + 4 * (f & 1) + (i & 3);
         voff[r] = rho * ldvt;
     }
-    const int nt = (p.Skv + KB - 1) / KB;
+    const int nt = (skv + KB - 1) / KB;
+    const int vlim = ldvt - 8 - key0;
     auto stage = [&](int t) {
         char* sK = smem + (t & (NSP - 1)) * STAGE;
         char* sV = sK + TILE;
         const int kv0 = t * KB;
-        int c = kv0 + schunk; if (c > ldvt - 8) c = ldvt - 8;       // fully masked chunk: any finite data
+        int c = kv0 + schunk; if (c > vlim) c = vlim;       // fully masked chunk: any finite data
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int off = (r * 4 + w) * 1024;
-            int key = kv0 + krow[r]; if (key > p.Skv - 1) key = p.Skv - 1;
+            int key = kv0 + krow[r]; if (key > skv - 1) key = skv - 1;
             glds16(Kb + (unsigned)(key * ldk + schunk), sK + off);
             glds16(Vb + (unsigned)(voff[r] + c), sV + off);
         }
@@ -241,7 +263,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= p.Skv) sc[f][qi][r] = -INFINITY;
+                        if (kv0 + 32 * (f >> 1) + 8 * fg + 4 * (f & 1) + r >= skv) sc[f][qi][r] = -INFINITY;
         }
         int im = 0x80000000;
         const char* sKn = smem + ((t + 1) & (NSP - 1)) * STAGE;
@@ -304,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
     };
 
     f32x4 sA[4][2], sB[4][2];
-    const bool tail_masked = (p.Skv % KB) != 0;
+    const bool tail_masked = (skv % KB) != 0;
     using T_ = std::true_type; using F_ = std::false_type;
     if (nt >= NSP - 1) wait_vmcnt<(NSP - 2) * LOADS>(); else if (nt == 2) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -339,6 +361,52 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_pipe_kernel(const AttnParams 
     }
 
     if (prof_on) pt2 = prof_now();
+    if (split) {
+        // publish this key range's (o, reference maximum, row sum) in the lane layout it is held in (nine 16-byte vectors per lane, written through to the
+        // coherence point), take a ticket; the item's last arriver re-reads ALL ranges in range order (so the sum does not depend on who arrives last)
+        const int nparts = 1 << p.lsplit, itail = bid - p.n_full;
+        f32x4* wsb = (f32x4*)p.ws + ((int64_t)(itail * nparts) * 4 + w) * (SPLIT_VEC * 64) + lane;      // range r: + r * 4 * SPLIT_VEC * 64
+        {
+            f32x4* dst = wsb + (int64_t)part * 4 * (SPLIT_VEC * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st_coherent(dst + i * 64, o[i >> 1][i & 1]);
+            st_coherent(dst + 8 * 64, (f32x4){negm[0][0], negm[1][0], lacc[0][0], lacc[1][0]});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = (unsigned*)smem;
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.tickets + itail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == (unsigned)(nparts - 1);
+            if (last) __hip_atomic_store(p.tickets + itail, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) { if (prof_on) prof_leave(p.prof, p.prof_detail, pt0, pt1, pt2); return; }
+        f32x4 st[SPLIT_MAX];
+#pragma unroll
+        for (int r = 0; r < SPLIT_MAX; ++r) if (r < nparts) st[r] = ld_coherent(wsb + (int64_t)r * 4 * (SPLIT_VEC * 64) + 8 * 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < SPLIT_MAX; ++r) if (r < nparts) { asm volatile("" : "+v"(st[r])); m0 = fmaxf(m0, -st[r][0]); m1 = fmaxf(m1, -st[r][1]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < SPLIT_MAX; ++r) {
+            if (r >= nparts) break;
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = ld_coherent(wsb + (int64_t)r * 4 * (SPLIT_VEC * 64) + i * 64);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float w0 = __builtin_amdgcn_exp2f(-st[r][0] - m0), w1 = __builtin_amdgcn_exp2f(-st[r][1] - m1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(v[i])); o[i >> 1][i & 1] += v[i] * ((i & 1) ? w1 : w0); }
+            l0 += st[r][2] * w0; l1 += st[r][3] * w1;
+        }
+        lacc[0][0] = l0; lacc[1][0] = l1;
+    }
     if (p.O8) {
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
@@ -529,10 +597,35 @@ __global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) 
 
 }  // namespace
 
+// Key-split tail: B * H * ceil(Sq / 128) items on 512 workgroup slots (two per CU).  When a last, partly filled round remains (SDXL: 640 items at S = 1024,
+// 1280 at S = 4096) its r items are cut into 512 / r key ranges, one workgroup each, so that the last round is 1 / split as long and fills every slot.
+struct AttnSplit { int n_full, lsplit, tpp, n_tail; int64_t ws_bytes; };
+static bool attn_split_plan(int B, int H, int Sq, int Skv, AttnSplit& sp) {
+    constexpr int SLOTS = 512, TICKET_BYTES = 4096;
+    if (Skv <= SK_MAX || (Skv % KB) || getenv("TMIX_ATTN_NO_SPLIT")) return false;
+    const int64_t items = (int64_t)((Sq + QB - 1) / QB) * B * H;
+    const int nt = Skv / KB;
+    const int r = (int)(items % SLOTS);
+    if (items <= SLOTS || r == 0 || (r & 7) || (SLOTS % r)) return false;
+    int split = SLOTS / r, lsplit = 0;
+    if (split > SPLIT_MAX) split = SPLIT_MAX;
+    while ((1 << lsplit) < split) ++lsplit;
+    if ((1 << lsplit) != split || (nt % split) || nt / split < 2 || r > TICKET_BYTES / 4) return false;
+    sp.n_full = (int)(items - r); sp.lsplit = lsplit; sp.tpp = nt / split; sp.n_tail = r;
+    sp.ws_bytes = TICKET_BYTES + (int64_t)r * split * 4 * SPLIT_VEC * 64 * 16;
+    return true;
+}
+
+extern "C" int64_t tmix_attn_split_ws_bytes(int B, int H, int Sq, int Skv) {
+    AttnSplit sp;
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return 0;
+    return attn_split_plan(B, H, Sq, Skv, sp) ? sp.ws_bytes : 0;
+}
+
 static int attn_entry(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
                       const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
                       void* O8, int64_t ldo8, void* Sc, int64_t ldSc,
-                      int B, int H, int Sq, int Skv, float scale, void* stream) {
+                      int B, int H, int Sq, int Skv, float scale, void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
     if (!Q || !K || !Vt || (!O && !O8)) TMIX_FAIL(TMIX_EINVAL, "attn: null pointer");
     if (O8) {
         if (!Sc || (ldo8 % 4) || ldo8 < (int64_t)H * 64 || ldSc < (int64_t)B * Sq || (((uintptr_t)O8) & 3))
@@ -573,8 +666,17 @@ static int attn_entry(const void* Q, int64_t ldq, int64_t strideQ, const void* K
         TMIX_LAUNCH_CHECK();
         return TMIX_OK;
     }
-    const int64_t nwg = (int64_t)p.nq * B * H;
+    int64_t nwg = (int64_t)p.nq * B * H;
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
+    p.n_full = (int)nwg; p.lsplit = 0; p.tpp = 0; p.ws = nullptr; p.tickets = nullptr;
+    AttnSplit sp;
+    if (ws && attn_split_plan(B, H, Sq, Skv, sp)) {
+        if ((((uintptr_t)ws) & 15) || ws_bytes < sp.ws_bytes)
+            TMIX_FAIL(TMIX_EINVAL, "attn: the key-split workspace needs %lld bytes (tmix_attn_split_ws_bytes), 16-byte aligned; got %lld", (long long)sp.ws_bytes, (long long)ws_bytes);
+        p.n_full = sp.n_full; p.lsplit = sp.lsplit; p.tpp = sp.tpp;
+        p.tickets = (unsigned*)ws; p.ws = (float*)((char*)ws + 4096);
+        nwg = (int64_t)sp.n_full + ((int64_t)sp.n_tail << sp.lsplit);
+    }
     attn_fwd_pipe_kernel<<<dim3((unsigned)nwg), 256, SMEM_P, (hipStream_t)stream>>>(p);
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
@@ -591,4 +693,19 @@ extern "C" int tmix_attn_fwd_f8(const void* Q, int64_t ldq, int64_t strideQ, con
                                 int B, int H, int Sq, int Skv, float scale, void* stream) {
     if (!O8) TMIX_FAIL(TMIX_EINVAL, "attn_f8: null output");
     return attn_entry(Q, ldq, strideQ, K, ldk, strideK, Vt, ldvt, strideVt, nullptr, 0, 0, O8, ldo8, scales, ldScale, B, H, Sq, Skv, scale, stream);
+}
+
+// The same two with a caller-owned workspace for the key-split tail (tmix_attn_split_ws_bytes; zero-filled once by the caller, left zeroed by every launch;
+// one workspace per stream that runs attention).  ws = NULL or a shape that does not split: exactly tmix_attn_fwd / tmix_attn_fwd_f8.
+extern "C" int tmix_attn_fwd_ws(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                                const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                                int B, int H, int Sq, int Skv, float scale, void* ws, int64_t ws_bytes, void* stream) {
+    return attn_entry(Q, ldq, strideQ, K, ldk, strideK, Vt, ldvt, strideVt, O, ldo, strideO, nullptr, 0, nullptr, 0, B, H, Sq, Skv, scale, stream, ws, ws_bytes);
+}
+
+extern "C" int tmix_attn_fwd_f8_ws(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                                   const void* Vt, int64_t ldvt, int64_t strideVt, void* O8, int64_t ldo8, void* scales, int64_t ldScale,
+                                   int B, int H, int Sq, int Skv, float scale, void* ws, int64_t ws_bytes, void* stream) {
+    if (!O8) TMIX_FAIL(TMIX_EINVAL, "attn_f8: null output");
+    return attn_entry(Q, ldq, strideQ, K, ldk, strideK, Vt, ldvt, strideVt, nullptr, 0, 0, O8, ldo8, scales, ldScale, B, H, Sq, Skv, scale, stream, ws, ws_bytes);
 }

@@ -372,25 +372,34 @@ def conv_out(x_nhwc, w_ohwi, bias, out=None):
     return out
 
 
-def attention(q, k, vt, H, Skv, scale, out=None, f8_out=None):
+def attention_split_ws(B, H, Sq, Skv, device):
+    """zero-filled workspace that lets tmix_attn_fwd_ws cut the items of a partly filled last round into key ranges (None: this shape does not split).
+    One per stream that runs attention; the launches leave its ticket counters at zero."""
+    n = L.load().tmix_attn_split_ws_bytes(B, H, Sq, Skv)
+    return torch.zeros(n, device=device, dtype=torch.uint8) if n > 0 else None
+
+
+def attention(q, k, vt, H, Skv, scale, out=None, f8_out=None, ws=None):
     """q [B,Sq,>=H*64] bf16 (row stride free), k [B,>=Skv,..] bf16, vt [B,H*64,ldvt] bf16 (V transposed).
-    f8_out: an F8Copy(B * Sq, H * 64) that receives the output as e4m3 + MX block scales INSTEAD of the bf16 tensor (tmix_attn_fwd_f8)."""
+    f8_out: an F8Copy(B * Sq, H * 64) that receives the output as e4m3 + MX block scales INSTEAD of the bf16 tensor (tmix_attn_fwd_f8).
+    ws: attention_split_ws(...) buffer (at least as large as this shape needs) -> the key-split tail (tmix_attn_fwd_ws / tmix_attn_fwd_f8_ws)."""
     _need_cuda(q, k, vt)
     lib = L.load()
     B, Sq = q.shape[0], q.shape[1]
     assert q.dtype == BF16 and k.dtype == BF16 and vt.dtype == BF16
     assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    wsa = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
     if f8_out is not None:
         assert f8_out.rows == B * Sq and f8_out.N == H * 64
-        L.check(lib.tmix_attn_fwd_f8(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0), _p(vt), vt.stride(1), vt.stride(0),
-                                     f8_out.q.data_ptr(), f8_out.N, f8_out.scales.data_ptr(), f8_out.rows,
-                                     B, H, Sq, Skv, float(scale), _stream()), "tmix_attn_fwd_f8")
+        L.check(lib.tmix_attn_fwd_f8_ws(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0), _p(vt), vt.stride(1), vt.stride(0),
+                                        f8_out.q.data_ptr(), f8_out.N, f8_out.scales.data_ptr(), f8_out.rows,
+                                        B, H, Sq, Skv, float(scale), *wsa, _stream()), "tmix_attn_fwd_f8_ws")
         return f8_out
     if out is None:
         out = torch.empty(B, Sq, H * 64, device=q.device, dtype=BF16)
-    L.check(lib.tmix_attn_fwd(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
-                              _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
-                              B, H, Sq, Skv, float(scale), _stream()), "tmix_attn_fwd")
+    L.check(lib.tmix_attn_fwd_ws(_p(q), q.stride(1), q.stride(0), _p(k), k.stride(1), k.stride(0),
+                                 _p(vt), vt.stride(1), vt.stride(0), _p(out), out.stride(1), out.stride(0),
+                                 B, H, Sq, Skv, float(scale), *wsa, _stream()), "tmix_attn_fwd_ws")
     return out
 
 

@@ -760,17 +760,31 @@ class UNetPlan:
     def _attn(self, q, k, vt, out, H, Sq, Skv, f8_out=None):
         """f8_out: an ops.F8Copy that receives the output as e4m3 + MX block scales instead of the bf16 tensor `out` (fp8 plans: the out-projection's
         A operand without a quantiser launch and with half the bytes)"""
+        # key-split tail (tmix_attn_fwd_ws), by request only (TMIX_ATTN_SPLIT=1): hot it takes 5 % off the S = 4096 launches and 2 % off S = 1024, in the
+        # captured step nothing (DESIGN.md 5b item 8) -- and a co-batched seed would no longer equal its single run bit for bit.  One zeroed workspace per
+        # launch shape of this chain (launches of a chain are serial on its stream)
+        ws = None
+        if os.environ.get("TMIX_ATTN_SPLIT"):
+            wss = getattr(self, "_attn_ws", None)
+            if wss is None:
+                wss = {}
+                setattr(self, "_attn_ws", wss)
+            wkey = (self.B, H, Sq, Skv)
+            if wkey not in wss:
+                wss[wkey] = ops.attention_split_ws(*wkey, q.device)
+            ws = wss[wkey]
+        wsa = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
         if f8_out is not None:
             args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
                     vt.data_ptr(), vt.stride(1), vt.stride(0), f8_out.q.data_ptr(), f8_out.N, f8_out.scales.data_ptr(), f8_out.rows,
-                    self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5)
-            self._emit(self.lib.tmix_attn_fwd_f8, *args)
+                    self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5, *wsa)
+            self._emit(self.lib.tmix_attn_fwd_f8_ws, *args)
             self.keep.append(f8_out)
         else:
             args = (q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0),
                     vt.data_ptr(), vt.stride(1), vt.stride(0), out.data_ptr(), out.stride(1), out.stride(0),
-                    self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5)
-            self._emit(self.lib.tmix_attn_fwd, *args)
+                    self.B, H, Sq, Skv, self.cfg.head_dim ** -0.5, *wsa)
+            self._emit(self.lib.tmix_attn_fwd_ws, *args)
         fl = 4 * self.B * H * Sq * Skv * 64
         self.flops += fl
         self.launches["attn"].append((args, fl))
