@@ -233,7 +233,7 @@ class I2VPlan(UNetPlan):
         self.fp8_conv, self.fp8_conv_tile = False, 0
         # GroupNorm statistics from the producers' column partials (UNetPlan._colstats) where 32-row blocks fit the normalised image: the per-frame norms of the
         # first two levels (5376 / 1344 pixels) and the clip-wide norms of TemporalConvLayer / TransformerTemporalModel up to CLIP_COLSTATS_MAX rows (16 frames x HW is
-        # always a multiple of 32); the first level's clip-wide norms (86,016 rows = 2688 partial blocks per channel) and the injection sites keep the statistics kernel
+        # always a multiple of 32: every level since round 5); per-frame norms of 336 / 84 pixels and the injection sites keep the statistics kernel
         self._gn_fused = not os.environ.get("TMIX_GN_STATS_KERNEL")
         self._sc_fused = not os.environ.get("TMIX_SHORTCUT_GEMM")      # conv_shortcut in conv2's launch, no concat launches (UNetPlan._resnet)
         self.lib, self.dev = L.load(), W.device
@@ -270,7 +270,9 @@ class I2VPlan(UNetPlan):
         assert temb.shape == (self.clips, Co)
         return temb, self.frames
 
-    CLIP_COLSTATS_MAX = 32768        # rows of a clip-wide norm whose combine launch walks the producers' partials (672 blocks per channel at the second level)
+    # rows of a clip-wide norm whose combine launch walks the producers' partials: all levels (first level at 16 x 768 x 448: 86,016 rows = 2688 blocks per channel,
+    # where the walk still beats the statistics kernel's pass over 110 MB: 74.94 -> 74.69 ms per step, 50 launches fewer; TMIX_CLIP_COLSTATS_MAX=32768 = round 4's limit)
+    CLIP_COLSTATS_MAX = int(os.environ.get("TMIX_CLIP_COLSTATS_MAX", "131072"))
 
     def _colstats(self, owner, rows, HW, Cc):
         """as UNetPlan._colstats, for two kinds of readers: per-frame norms (HW pixels per image) and clip-wide norms (frames x HW rows per image)"""
