@@ -133,6 +133,27 @@ def timed_fusion_steps(tw, args, world, device, x):
     return dt, tw.x_state.clone()
 
 
+def chip_state_under_load(tw, device, x, n_steps=40, samples=4):
+    """shader clock / socket power / temperature while the SAME captured step replays (untimed, behind the value window): boxes of the pool differ by up to 8 %
+    with identical code, every kernel class moving together -- this says what state the chip held.  None where the SMI library is missing."""
+    from tweediemix_amd import lib as L
+    ts = fusion_timesteps(tw)
+    tw.x_state.copy_(x)
+    try:
+        for i in range(n_steps):
+            t = ts[i % len(ts)]
+            tw._run_step("fusion", L.STEP_FUSION, t, tw.alpha(t), tw.alpha(t - tw.skip))
+        clk, pw, tc = [], [], []
+        for _ in range(samples):
+            time.sleep(0.15)
+            clk.append(int(torch.cuda.clock_rate(device))); pw.append(int(torch.cuda.power_draw(device))); tc.append(int(torch.cuda.temperature(device)))
+        torch.cuda.synchronize()
+        return {"sclk_mhz": clk, "power_raw": pw, "temp_c": tc, "what": f"torch.cuda.clock_rate / power_draw (the unit is the SMI library's: W on this image) / temperature, sampled 150 ms apart while {n_steps} more replays of the timed step were in flight (outside every timed window)"}
+    except Exception as e:      # noqa: BLE001 -- a diagnostic, never fatal
+        torch.cuda.synchronize()
+        return {"error": repr(e)[:200]}
+
+
 def parity_check(tw, args, parts, kind, device):
     """the timed path (hipGraph replay, two launch chains, shipped tile table) against an eager single-chain run of the SAME
     step from the same latent: rel-L2 of the updated latent (the tilings differ, so LayerNorm partial sums are added in a
@@ -630,6 +651,7 @@ def main(argv=None):
     traj = None if args.no_trajectory else run_trajectories(tw, args, rank, world, device)
     dt, _x = timed_fusion_steps(tw, args, world, device, x)
     dt = D.max_over_ranks(dt, cdev)
+    chip = chip_state_under_load(tw, device, x) if rank == 0 else None
 
     other = {}
     if args.kind == "both" and world == 1:
@@ -681,6 +703,7 @@ def main(argv=None):
             "first_window": {"ms_per_step": 1e3 * dt_first / (args.steps * S_), "value": world * S_ * args.steps / dt_first,
                              "what": "the same W + K steps timed right behind the plan build (rounds 1-4 reported this window); `value` is the window at the end of the "
                                      "run, after >= 3 s of load (parity check, in-situ profile, trajectories): the state the chip holds through a 2 s trajectory"},
+            "chip_state_under_load": chip,
             "config": {"workload": f"SDXL-base UNet shapes, {args.res}x{args.res}, K=3 concepts ({primary} deltas"
                                    + (", --t_stop 0.8 window" if primary == "lora" else "") + "), "
                                    f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel, one hipGraph per step"
