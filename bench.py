@@ -503,13 +503,21 @@ def video_step_bench(steps=8, warmup=2, res_w=768, res_h=448, frames=16, streams
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t1) / steps
     assert torch.isfinite(x).all()
-    names = [getattr(fn, "__name__", "") for fn, _a in plan.ops]
-    kernels = sum(0 if n == "tmix_gemm_prefetch_next" else 3 if n == "tmix_groupnorm_nhwc" else 2 if n.startswith("tmix_groupnorm_nhwc_pre") else 1 for n in names) + 1
+    from tweediemix_amd import lib as L_
+
+    def n_kernels(fn, a):
+        n = getattr(fn, "__name__", "")
+        if n == "tmix_gemm_prefetch_next":
+            return 0
+        if n == "tmix_groupnorm_nhwc":            # (x1, C1, x2, C2, out, gamma, beta, ws, B, HW, groups, eps, silu): three launches, or one for small images
+            return L_.load().tmix_groupnorm_nhwc_launches(a[9], a[1] + a[3], a[10])
+        return 2 if n.startswith("tmix_groupnorm_nhwc_pre") else 1
+    kernels = sum(n_kernels(fn, a) for fn, a in plan.ops) + 1
     res = {"workload": f"BASELINE configs[4]: I2VGen-XL (1.42 B parameters, synthetic), {frames} frames {res_w}x{res_h}, CFG pair = 2 clips, "
                        f"{streams} launch chain(s), one denoising step = UNet + fused CFG/v-prediction/DDIM kernel, hipGraph replay",
            "value": 1e3 / ms, "unit": "steps/s", "ms_per_step": ms, "unet_tflop_per_step": plan.flops / 1e12,
            "achieved_tflops": plan.flops / ms / 1e9, "seconds_per_50_step_video": 50 * ms / 1e3, "launches_per_step": kernels,
-           "launches_what": "GPU kernels per step (a GroupNorm call is three: statistics, combine, apply; the weight-prefetch hints in the op list are host-side only)",
+           "launches_what": "GPU kernels per step (a GroupNorm call is three -- statistics, combine, apply --, two on the producers' partials, one for small frames; the weight-prefetch hints in the op list are host-side only)",
            "plan_build_s": build_s, "dtype": "bf16"}
     del plan, Wt
     torch.cuda.empty_cache()

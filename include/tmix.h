@@ -303,6 +303,10 @@ int tmix_groupnorm_ws_chunks(int64_t HW);   /* statistics workgroups per image (
 int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                         const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
                         void* stream);
+/* kernels one tmix_groupnorm_nhwc call issues for an image of HW pixels and C channels: 3 (statistics, combine, apply) or 1 -- images whose slice of a few groups
+ * (HW x 8..256 channels <= 64 K elements: the 336- / 84-pixel frames of video_gen/pipeline_i2vgen_xl.py:680-722's third and fourth levels) is small are normalised by one
+ * workgroup per (image, group set) in a single launch.  A function of the image's shape only, never of the batch. */
+int tmix_groupnorm_nhwc_launches(int64_t HW, int C, int groups);
 /* The same normalisation with the statistics pass replaced by the column partials the PRODUCERS of the tensor left behind
  * (tmix_gemm_desc.col_stats_out / tmix_conv_desc.col_stats_out): cs1 = fp32 [B*HW / 32][2][cs1_channels] covers channels
  * [0, cs1_channels), cs2 (NULL with cs2_channels = 0) the cs2_channels behind them; cs1_channels + cs2_channels = C1 + C2.  The split of

@@ -494,6 +494,31 @@ def test_attention_key_split_applies_to_partly_filled_last_rounds_only(ops):
 
 
 # --------------------------------------------------------------------------- norms / small ops
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(32, 336, 1280, 0, True), (32, 84, 1280, 0, False), (32, 336, 1280, 640, True), (8, 1344, 320, 0, True),
+                                             (3, 84, 640, 320, True), (2, 1024, 320, 320, False), (1, 100, 64, 0, True)])
+def test_groupnorm_of_small_images_in_one_launch(ops, monkeypatch, B, HW, C1, C2, silu):
+    """tmix_groupnorm_nhwc on images whose (HW x channels of a few groups) slice is small runs statistics + apply in ONE launch, one workgroup per (image, group set)
+    (the video UNet's 336- / 84-pixel frames).  Against torch, against the three-launch form (TMIX_GN_NO_SMALL=1: same statistics up to fp32 summation order), and
+    batch-independent: an image's bits do not depend on how many images share the launch."""
+    x1 = rnd(B, HW, C1, seed=54) * 1.5 + 0.5
+    x2 = rnd(B, HW, C2, seed=55) * 2 - 0.25 if C2 else None
+    Cc = C1 + C2
+    g, b = rnd(Cc, seed=56, dtype=torch.float32), rnd(Cc, seed=57, dtype=torch.float32)
+    y = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], -1)
+    ref = F.group_norm(xin.transpose(1, 2), 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref.transpose(1, 2), rtol=2 ** -6, atol_frac=4e-3)
+    y1 = ops.groupnorm(x1[:1].contiguous(), g, b, 32, 1e-5, silu, x2=None if x2 is None else x2[:1].contiguous())
+    assert torch.equal(y1, y[:1])
+    monkeypatch.setenv("TMIX_GN_NO_SMALL", "1")
+    y3 = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2)
+    torch.cuda.synchronize()
+    d = (y.float() - y3.float()).abs()
+    assert float(d.max()) <= 2 ** -6 * float(y3.float().abs().max())
+
+
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (1, 100, 64, 0, False), (2, 64, 640, 320, True),
                                              (1, 1024, 1280, 1280, True), (4, 16, 32, 0, False)])
 def test_groupnorm(ops, B, HW, C1, C2, silu):

@@ -264,6 +264,113 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
     if (prof && threadIdx.x == 0) prof_leave(prof, 0, pt0, pt0, pt0);
 }
 
+// GroupNorm (+ SiLU) of a SMALL image in ONE launch (tmix_groupnorm_nhwc picks it by shape): one workgroup owns gpw consecutive groups of one image -- cw = gpw * C / groups
+// channels, a multiple of 8 -- reads its HW x cw slice twice (statistics, then apply: <= 128 KB, it stays in L2) and needs nobody else's sums.  The three-launch form costs a
+// 336-pixel frame of the video UNet's third level 10 + 5 + 10 us and two kernel boundaries; the slices here are 27 - 80 KB.  Thread t keeps vector t % nv of rows t / nv,
+// + rs, ...; the sums meet in LDS and are added in a fixed order (channel sums over row slots, then group sums over channels, both in fp64): every output bit is a function
+// of the image alone, as with the other forms.
+constexpr int GN_SMALL_MAX_CW = 256, GN_SMALL_MAX_ELEMS = 65536;
+__global__ void __launch_bounds__(256) gn_small_kernel(const bf16_t* __restrict__ X1, int C1, const bf16_t* __restrict__ X2, int C2, bf16_t* __restrict__ Y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int groups, int gpw, float eps, int silu,
+                                                       unsigned long long* prof) {
+    __shared__ float r_s[2048], r_q[2048];
+    __shared__ double c_s[GN_SMALL_MAX_CW], c_q[GN_SMALL_MAX_CW];
+    __shared__ float g_ms[16];
+    __shared__ float2 s_ss[GN_SMALL_MAX_CW];
+    const unsigned long long pt0 = (prof && threadIdx.x == 0) ? prof_now() : 0;
+    const int C = C1 + C2, cpg = C / groups, cw = gpw * cpg, nv = cw >> 3, rs = 256 / nv;
+    const int b = blockIdx.y, c0 = blockIdx.x * cw, tid = threadIdx.x;
+    const int v = tid % nv, slot = tid / nv;
+    const bool active = slot < rs;
+    const int cg = c0 + v * 8;
+    const bf16_t* src; int ld;
+    if (cg < C1) { src = X1 + (int64_t)b * HW * C1 + cg; ld = C1; } else { src = X2 + (int64_t)b * HW * C2 + (cg - C1); ld = C2; }
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (active) {
+        int row = slot;
+        for (; row + 3 * rs < HW; row += 4 * rs) {                 // four rows in flight
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (int64_t)(row + u * rs) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8]; unpack8(raw[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+        }
+        for (; row < HW; row += rs) {
+            float f[8]; unpack8(*(const uint4*)(src + (int64_t)row * ld), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r_s[slot * cw + v * 8 + j] = s[j]; r_q[slot * cw + v * 8 + j] = q[j]; }
+    }
+    __syncthreads();
+    if (tid < cw) {
+        double a = 0.0, d = 0.0;
+        for (int k = 0; k < rs; ++k) { a += (double)r_s[k * cw + tid]; d += (double)r_q[k * cw + tid]; }
+        c_s[tid] = a; c_q[tid] = d;
+    }
+    __syncthreads();
+    if (tid < gpw) {
+        double a = 0.0, d = 0.0;
+        for (int k = 0; k < cpg; ++k) { a += c_s[tid * cpg + k]; d += c_q[tid * cpg + k]; }
+        const double n = (double)HW * cpg, mean = a / n;
+        double var = d / n - mean * mean; if (var < 0.0) var = 0.0;
+        g_ms[2 * tid] = (float)mean; g_ms[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (tid < cw) {
+        const int g = tid / cpg;
+        const float sc = g_ms[2 * g + 1] * gamma[c0 + tid];
+        s_ss[tid] = make_float2(sc, beta[c0 + tid] - g_ms[2 * g] * sc);
+    }
+    __syncthreads();
+    if (active) {
+        float2 k[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = s_ss[v * 8 + j];
+        bf16_t* dst = Y + (int64_t)b * HW * C + cg;
+        int row = slot;
+        for (; row + 3 * rs < HW; row += 4 * rs) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (int64_t)(row + u * rs) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8]; unpack8(raw[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float y = f[j] * k[j].x + k[j].y; if (silu) y = silu_fast(y); f[j] = y; }
+                *(uint4*)(dst + (int64_t)(row + u * rs) * C) = pack8(f);
+            }
+        }
+        for (; row < HW; row += rs) {
+            float f[8]; unpack8(*(const uint4*)(src + (int64_t)row * ld), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float y = f[j] * k[j].x + k[j].y; if (silu) y = silu_fast(y); f[j] = y; }
+            *(uint4*)(dst + (int64_t)row * C) = pack8(f);
+        }
+    }
+    if (prof && threadIdx.x == 0) prof_leave(prof, 0, pt0, pt0, pt0);
+}
+// gpw for the one-launch form, or 0 when the shape does not qualify (the slice must be small).  A function of the image's shape ONLY -- not of the batch: co-batched seeds
+// and row-split chains must take the same path as a single run to reproduce it bit for bit.
+static int gn_small_gpw(int64_t HW, int C, int groups) {
+    if (getenv("TMIX_GN_NO_SMALL")) return 0;
+    const int cpg = C / groups;
+    for (int gpw = 1; gpw <= 8; gpw <<= 1) {
+        if (groups % gpw || ((gpw * cpg) & 7)) continue;
+        const int cw = gpw * cpg;
+        if (cw > GN_SMALL_MAX_CW || HW * cw > GN_SMALL_MAX_ELEMS) return 0;
+        return gpw;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ LayerNorm
 // one wave per row, row kept in registers (exact two-pass variance); C <= 2048, C % 8 == 0
 __global__ void __launch_bounds__(256) layernorm_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
@@ -558,6 +665,11 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const bf16_t* __restrict_
 extern "C" int tmix_groupnorm_ws_chunks(int64_t HW) { return gn_chunks(HW); }
 extern "C" int64_t tmix_groupnorm_ws_floats(int B, int C, int groups) { return (int64_t)B * GN_T * groups * 2 + (int64_t)B * C * 2; }
 
+extern "C" int tmix_groupnorm_nhwc_launches(int64_t HW, int C, int groups) {
+    if (HW <= 0 || C <= 0 || groups <= 0 || (C % groups)) return 0;
+    return gn_small_gpw(HW, C, groups) ? 1 : 3;
+}
+
 extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C2, void* Y, const float* gamma,
                                    const float* beta, float* ws, int B, int64_t HW, int groups, float eps, int silu,
                                    void* stream) {
@@ -570,6 +682,11 @@ extern "C" int tmix_groupnorm_nhwc(const void* X1, int C1, const void* X2, int C
     const int chunks = gn_chunks(HW);
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* prof = tmix_prof_take();
+    if (const int gpw = gn_small_gpw(HW, C, groups)) {          // small images: statistics + apply in one launch, one workgroup per (image, gpw groups)
+        gn_small_kernel<<<dim3(groups / gpw, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, (bf16_t*)Y, gamma, beta, (int)HW, groups, gpw, eps, silu, prof);
+        TMIX_LAUNCH_CHECK();
+        return TMIX_OK;
+    }
     gn_stats_kernel<<<dim3(chunks, B), 256, 0, st>>>((const bf16_t*)X1, C1, (const bf16_t*)X2, C2, ws, HW, groups, chunks, prof);
     TMIX_LAUNCH_CHECK();
     // ws layout: [B*chunks*groups*2] partial sums | [B*C] float2 scale/shift

@@ -89,6 +89,7 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, i64, vp]),
     "tmix_attn_fwd_f8_ws": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, vp, i64,
                                       C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, i64, vp]),
+    "tmix_groupnorm_nhwc_launches": (C.c_int, [i64, C.c_int, C.c_int]),
     "tmix_groupnorm_ws_chunks": (C.c_int, [i64]),
     "tmix_groupnorm_ws_floats": (i64, [C.c_int, C.c_int, C.c_int]),
     "tmix_groupnorm_nhwc": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, i64, C.c_int, f32,
