@@ -120,6 +120,19 @@ def test_argument_errors_are_reported_before_any_launch():
     u8 = lambda a: C.cast(C.c_void_p(a), C.POINTER(C.c_uint8))
     assert l.tmix_gemm_fp8(C.byref(d), u8(0x5000), u8(0x6000), None) == lib.EINVAL and b"tile_cfg" in l.tmix_last_error_string()     # 160-wide tiles cannot end MX blocks of the GEGLU output
 
+    # round 5 host rules (pure functions of the shape, no device): the self-attention key split applies to partly filled last rounds only ...
+    W = lambda r, parts: 4096 + r * parts * 4 * 9 * 64 * 16
+    assert l.tmix_attn_split_ws_bytes(4, 20, 1024, 1024) == W(128, 4) and l.tmix_attn_split_ws_bytes(4, 10, 4096, 4096) == W(256, 2)      # SDXL attn1 at 1024^2, B = 4
+    assert l.tmix_attn_split_ws_bytes(8, 20, 1024, 1024) == W(256, 2) and l.tmix_attn_split_ws_bytes(1, 20, 4096, 4096) == W(128, 4)
+    for shape in [(2, 20, 1024, 1024), (16, 20, 1024, 1024), (4, 20, 1024, 77), (4, 20, 1024, 1000), (1, 1, 128, 128), (4, 20, 1024, 64), (0, 20, 1024, 1024)]:
+        assert l.tmix_attn_split_ws_bytes(*shape) == 0, shape
+    assert l.tmix_attn_fwd_ws(fake, 1280, 1280 * 1024, fake, 1280, 1280 * 1024, fake, 1024, 1280 * 1024, None, 1280, 1280 * 1024, 4, 20, 1024, 1024, 0.125, fake, 1 << 30, None) == lib.EINVAL
+    # ... and tmix_groupnorm_nhwc takes the one-launch form by the IMAGE's shape alone (a few groups' slice of at most 64 K elements)
+    for (hw, c), n in {(336, 1280): 1, (84, 1280): 1, (336, 1920): 1, (1344, 320): 1, (100, 64): 1, (84, 2560): 1, (5376, 320): 3, (1024, 2560): 3, (16384, 320): 3, (1024, 1280): 1,
+                       (4096, 640): 3}.items():
+        assert l.tmix_groupnorm_nhwc_launches(hw, c, 32) == n, (hw, c)
+    assert l.tmix_groupnorm_nhwc_launches(0, 320, 32) == 0 and l.tmix_groupnorm_nhwc_launches(64, 100, 32) == 0
+
     # the once-per-video conditioning kernels of the I2VGen-XL path (csrc/conditioning.hip)
     assert l.tmix_conv3x3_f32(fake, fake, None, fake, 1, 4, 8, 8, 16, 3, 0, None) == lib.ESHAPE and b"stride" in l.tmix_last_error_string()
     assert l.tmix_conv3x3_f32(fake, None, None, fake, 1, 4, 8, 8, 16, 1, 0, None) == lib.EINVAL
