@@ -59,6 +59,10 @@ def parse(argv=None):
     ap.add_argument("--traj-cobatch", type=int, default=8, help="independent seeds sharing every UNet launch in the images/s measurement (8 = one GPU's share of BASELINE "
                                                                 "config 4: 64 seeds over 8 GPUs; 0.626 vs 0.613 images/s with 4, same box)")
     ap.add_argument("--traj-images", type=int, default=8, help="images per rank in the images/s measurement (ignored with --num-seeds)")
+    ap.add_argument("--masks", default="partition", choices=["partition", "overlap"],
+                    help="synthetic stand-in for the segmentation side-car: 'partition' = rectangles that do not intersect (blend weights sum to 1: the latent keeps its "
+                         "scale through the fusion window); 'overlap' = rounds 1-5's intersecting rectangles (the reference does not normalise, fusion_sampling.py:466-469: "
+                         "weights sum to 2 on the overlap and that region doubles every fusion step).  The line times BOTH; `value` is this one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip other_configs.video (BASELINE configs[4], one I2VGen-XL step)")
     ap.add_argument("--cpu-threads", type=int, default=64)
@@ -83,8 +87,8 @@ def build_sampler(args, kind, device, seed, fp8=None):
     conf = S.make_config(guidance_scale=0.8, n_timesteps=50, t_cond=0.2, t_stop=0.8, resampling_steps=10,
                          jumping_steps=5, resolution_h=args.res, resolution_w=args.res, seed=seed)
 
-    def mask_set(i):
-        return M.build_masks(M.random_rectangle_masks(K, args.res, args.res, seed=1000 * seed + i), h, w, device)
+    def mask_set(i, mask_kind=None):
+        return M.build_masks(M.synthetic_masks(mask_kind or getattr(args, "masks", "partition"), K, args.res, args.res, seed=1000 * seed + i), h, w, device)
 
     turn = [0]
 
@@ -96,7 +100,8 @@ def build_sampler(args, kind, device, seed, fp8=None):
                       n_seeds=S_, n_streams=args.streams, fp8=(getattr(args, "dtype", "bf16") == "fp8") if fp8 is None else fp8)
     tw.min_rows_per_stream = int(os.environ.get("TMIX_MIN_ROWS_PER_STREAM", str(tw.min_rows_per_stream)))
     tw.init_fusion(int(50 * 0.2), int(50 * 0.8)) if kind == "lora" else tw.init_fusion(int(50 * 0.2))
-    tw.masks = mask_set(0) if S_ == 1 else torch.stack([mask_set(i) for i in range(S_)]).contiguous()
+    tw.mask_sets = lambda mask_kind=None: mask_set(0, mask_kind) if S_ == 1 else torch.stack([mask_set(i, mask_kind) for i in range(S_)]).contiguous()
+    tw.masks = tw.mask_sets()
     return tw, (sd, con, te, ts, cfg)
 
 
@@ -105,12 +110,16 @@ def fusion_timesteps(tw):
 
 
 def timed_fusion_steps(tw, args, world, device, x):
-    """W warm-up + K timed fusion steps (barrier + synchronize on both sides).  Returns (seconds, final latent)."""
+    """W warm-up + K timed fusion steps (barrier + synchronize on both sides).  Returns (seconds, final latent).
+    The steps walk the fusion window's timesteps in order; when the walk wraps around to the window's first timestep the latent is re-seeded from `x`
+    (one 4*h*w-float device copy per pass through the window), so every step sees a latent of the scale its timestep has in a trajectory."""
     from tweediemix_amd import lib as L
     ts = fusion_timesteps(tw)
     tw.x_state.copy_(x)
 
     def step(i):
+        if i % len(ts) == 0:
+            tw.x_state.copy_(x)
         t = ts[i % len(ts)]
         tw._run_step("fusion", L.STEP_FUSION, t, tw.alpha(t), tw.alpha(t - tw.skip))
 
@@ -130,6 +139,7 @@ def timed_fusion_steps(tw, args, world, device, x):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(tw.x_state).all()
+    tw.last_window_max_abs_latent = float(tw.x_state.abs().max())
     return dt, tw.x_state.clone()
 
 
@@ -366,7 +376,7 @@ def run_trajectories(tw, args, rank, world, device):
 
         def provider(x0):                   # one rectangle set per seed, in the order the sampler asks
             turn[0] += 1
-            return M.build_masks(M.random_rectangle_masks(K, args.res, args.res, seed=31 * rank + turn[0]), tw.h, tw.w, device)
+            return M.build_masks(M.synthetic_masks(args.masks, K, args.res, args.res, seed=31 * rank + turn[0]), tw.h, tw.w, device)
         t = S.Tweediemix(tw.config, tw.W, tw.text_embeds, tw.text_embeds_single, provider, concept_num=K, lora=tw.lora,
                          use_graphs=tw.use_graphs, n_seeds=n_seeds, n_streams=tw.n_streams, vae=vae, fp8=tw.fp8)
         return t
@@ -659,7 +669,19 @@ def main(argv=None):
     traj = None if args.no_trajectory else run_trajectories(tw, args, rank, world, device)
     dt, _x = timed_fusion_steps(tw, args, world, device, x)
     dt = D.max_over_ranks(dt, cdev)
+    max_abs_latent = tw.last_window_max_abs_latent
     chip = chip_state_under_load(tw, device, x) if rank == 0 else None
+    # the same window once more on the OTHER synthetic mask kind, same process, same graph (the masks live at a fixed address the captured step reads), chip state
+    # beside it: rounds 1-5 timed intersecting rectangles, on which the un-normalised blend doubles the overlap region every fusion step
+    other_kind = "overlap" if args.masks == "partition" else "partition"
+    tw.masks = tw.mask_sets(other_kind)
+    dt_o, _xo = timed_fusion_steps(tw, args, world, device, x)
+    dt_o = D.max_over_ranks(dt_o, cdev)
+    other_masks = {"masks": other_kind, "ms_per_step": 1e3 * dt_o / (args.steps * args.seeds_per_gpu), "value": world * args.seeds_per_gpu * args.steps / dt_o,
+                   "max_abs_latent_at_end_of_window": tw.last_window_max_abs_latent,
+                   "chip_state_under_load": chip_state_under_load(tw, device, x) if rank == 0 else None,
+                   "what": "the same W + K steps, same captured graph, right behind the `value` window, with the other synthetic mask kind"}
+    tw.masks = tw.mask_sets()
 
     other = {}
     if args.kind == "both" and world == 1:
@@ -712,10 +734,17 @@ def main(argv=None):
                              "what": "the same W + K steps timed right behind the plan build (rounds 1-4 reported this window); `value` is the window at the end of the "
                                      "run, after >= 3 s of load (parity check, in-situ profile, trajectories): the state the chip holds through a 2 s trajectory"},
             "chip_state_under_load": chip,
+            "max_abs_latent_at_end_of_window": max_abs_latent,
+            "other_mask_kind_window": other_masks,
             "config": {"workload": f"SDXL-base UNet shapes, {args.res}x{args.res}, K=3 concepts ({primary} deltas"
                                    + (", --t_stop 0.8 window" if primary == "lora" else "") + "), "
                                    f"fusion-phase step = UNet B={K + 1} + fused Tweedie/CFG/blend/DDIM kernel, one hipGraph per step"
                                    + (" [TINY DEBUG CONFIG]" if args.tiny else ""),
+                       "masks": f"{args.masks}: synthetic rectangles " + ("that partition the image (fg_1 + fg_2 + bg = 1 on every pixel)" if args.masks == "partition"
+                                                                            else "that may intersect (un-normalised blend weights sum to 2 on the overlap)"),
+                       "value_window": "end of run (sustained state); first_window_ms_per_step = the same W + K steps right behind the plan build (what rounds 1-4 reported)",
+                       "first_window_ms_per_step": 1e3 * dt_first / (args.steps * S_),
+                       "other_mask_kind_ms_per_step": other_masks["ms_per_step"],
                        "seeds_per_gpu": S_, "streams": args.streams, "hip_graph": not args.no_graphs,
                        "parallelism": f"replicas x{world} (seed-sharded, no data-path collective)", "tilings": tilings},
             "dist": {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": world, "ranks_seen": ranks_seen,
@@ -729,7 +758,10 @@ def main(argv=None):
             "parity_check": check,
             "roofline": {"bound": "mfma", "kernel": "gemm_conv_kernel<..,CONV=0> (tmix_gemm_bf16)" if g is prof.get("gemm") else "gemm_conv_kernel<..,PH=2|3> (tmix_gemm_fp8)",
                          "achieved": g["tflops"], "peak": peak_tf, "unit": "TFLOP/s", "frac": g["tflops"] / peak_tf,
-                         "traffic": pmc[0], "pmc": pmc[1], "algorithmic_bytes_per_launch": alg,
+                         "traffic": pmc[0],
+                         "traffic_source": "NOT measured in this run: read from the committed rocprofv3 PMC passes named in profiles/MANIFEST.json (the builder's box, same command; "
+                                           "counters cannot be read from inside the process) -- see pmc.files",
+                         "pmc": pmc[1], "algorithmic_bytes_per_launch": alg,
                          "how": "achieved = sum(2MNK of the step's GEMM launches, plus the 4*M*77*N attention flops of the one-launch attn2 -- tmix_gemm_q_cross_attn -- which that launch performs) / sum(their durations), each launch timed on the device clock "
                                 "INSIDE the captured step while the graph replays (concurrent chains included, so the sum can exceed the wall time)",
                          "launches_per_step": g["launches"], "avg_launch_us": g["avg_launch_us"], "flops_per_step": g["flops"],

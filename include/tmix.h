@@ -34,6 +34,10 @@ int tmix_version(void);
 const char* tmix_last_error_string(void);
 /* 0 if the current device is gfx950, TMIX_EARCH otherwise, >0 on HIP errors. */
 int tmix_check_device(void);
+/* The library's debug / A-B environment switches (TMIX_GN_NO_SMALL, TMIX_ATTN_NO_SPLIT, TMIX_ATTN_GENERAL, TMIX_NARROW_EPILOGUE) are read ONCE per process, on first
+ * use, so that a launch, the query that accounts for it (tmix_groupnorm_nhwc_launches, tmix_attn_split_ws_bytes) and a captured graph all see one value.  This re-reads
+ * them (a test that flips a switch mid-process).  No reference counterpart. */
+void tmix_env_refresh(void);
 
 /* In-situ launch timing (measurement only; no reference counterpart).  Between tmix_prof_begin and tmix_prof_end every
  * tmix_gemm_bf16 / tmix_conv3x3_nhwc / tmix_attn_fwd / tmix_groupnorm_nhwc launch issued by THIS host thread -- also while
@@ -122,9 +126,8 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
        TMIX_TILE_256x320_PH = 22 /* 256x320 with the phase-offset mainloop (eight waves of 64x160): bf16 GEMM, no transposed region */,
        TMIX_TILE_128x160_W22 = 23 /* 128x160 over 2 x 2 math waves of 64x80 (16x16x32 MFMA) + four loader waves: 72 KB instead of 96 KB of LDS fragment reads per K-tile;
                                       plain staged bf16 epilogue (bias, folded LayerNorm, residual, row statistics) -- other launches run as tiling 21 */,
-       TMIX_TILE_256x320_P = 24 /* tiling 14 (256x320, eight waves) on PERSISTENT workgroups, one per CU: the next tile's first K-tile is requested under the current tile's last one;
-                                    the staged GEGLU epilogue on whole tiles (M %% 256 == 0, N %% 320 == 0), shared weights -- other launches run as tiling 14; same bits as 14 */,
-       TMIX_TILE_128x160_W22_PF = 25 /* tiling 23 with three DMA loader waves and one L2 PREFETCHER wave that touches the tile's A / W lines eight K-tiles ahead of the LDS ring */,
+       /* ids 24 and 25 are RESERVED: two measured-and-rejected experiments (256x320 on persistent workgroups; tiling 23 with an L2 prefetcher wave) that only dev
+          builds contain (make EXPERIMENTAL=1, tools/build_variant.sh); the shipped library runs them as tilings 14 and 23, whose bits they reproduce */
        TMIX_TILE_COUNT = 25 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */

@@ -39,3 +39,17 @@ def sdxl_weights():
         pytest.skip("needs a GPU")
     from tweediemix_amd import unet as U, weights as Wt
     return Wt.synthetic_state_dict(U.SDXL, seed=1234, device="cuda", dtype=torch.float32)
+
+
+@pytest.fixture(scope="session")
+def sdxl_bundles(sdxl_weights):
+    """kind -> (concept state dicts, product UNetWeights, fp32 UNetOracle) on the session's SDXL weights, built once per kind ('lora' merged sets /
+    'custom'): the per-concept merges and the kernel-layout conversion of 2.57 B parameters are the same for every full-size test."""
+    from trajectory_parity import sdxl_bundle
+    cache = {}
+
+    def get(kind):
+        if kind not in cache:
+            cache[kind] = sdxl_bundle(sdxl_weights, kind)
+        return cache[kind]
+    return get

@@ -298,3 +298,39 @@ def test_gather_without_a_process_group_is_an_error_when_there_are_other_ranks()
     assert D.gather_latents(x, 2, 0, 1) is x
     with pytest.raises(AssertionError):
         D.gather_latents(x, 4, 0, 2)
+
+
+def test_partition_masks_are_a_convex_blend_and_keep_the_oracle_latent_bounded():
+    """masks.partition_rectangle_masks: fg_1 + fg_2 + bg == 1 on every latent pixel (the blend of fusion_sampling.py:466-469 is then a convex
+    combination), whereas random_rectangle_masks can intersect (weights sum to 2: the reference does not normalise, the region doubles every
+    fusion step).  The second half replays the oracle's whole sampler on a stand-in eps = sqrt(1 - alpha_t) x (the ideal denoiser of unit-variance data): max|x| stays O(10)
+    with partition masks and explodes with the overlapping set -- which is why bench.py and the trajectory tolerance default to the former."""
+    from oracle import tweedie_oracle as TO
+    from tweediemix_amd import masks as M
+    K = 3
+    some_overlap = False
+    for res, hw in ((1024, 128), (512, 64)):
+        for seed in range(12):
+            m = M.build_masks(M.partition_rectangle_masks(K, res, res, seed), hw, hw, device="cpu")
+            s = m.sum(0)
+            assert m.shape == (K, 1, hw, hw) and float(s.min()) == 1.0 and float(s.max()) == 1.0
+            assert all(float(m[c].mean()) >= 0.04 for c in range(K - 1)), "a foreground region must survive the carve-out"
+            so = M.build_masks(M.random_rectangle_masks(K, res, res, seed), hw, hw, device="cpu").sum(0)
+            some_overlap |= float(so.max()) == 2.0
+    assert some_overlap
+    assert M.synthetic_masks("partition", K, 64, 64, 1)[0].dtype == np.uint8
+    with pytest.raises(ValueError):
+        M.synthetic_masks("nope", K, 64, 64)
+
+    seed = next(s for s in range(64) if float((M.build_masks(M.random_rectangle_masks(K, 256, 256, s), 32, 32, device="cpu").sum(0) > 1).float().mean()) > 0.03)
+    rowscale = (1 + 0.02 * np.arange(4, dtype=np.float32))[:, None, None, None]     # stand-in eps = E[noise | x_t] of unit-variance data, slightly different per prompt row
+
+    def run(kind):
+        imgs = M.synthetic_masks(kind, K, 256, 256, seed=seed)
+        o = TO.TweedieOracle(K, 20, g=0.8, t_cond=0.2, t_stop=0.8, resampling_steps=2, jumping_steps=2, mask_fn=lambda: TO.build_masks(imgs, 32, 32))
+        x = np.random.RandomState(0).randn(1, 4, 32, 32).astype(np.float32)
+        for t in o.sch.timesteps:
+            x = o.denoise_step(x, int(t), lambda xin, t_, rows, k, routed: (np.sqrt(1 - o.sch.alpha(t_)) * xin * rowscale[:xin.shape[0]]).astype(np.float32))
+        return float(np.abs(x).max())
+    bounded, exploding = run("partition"), run("overlap")
+    assert bounded < 10.0 and exploding > 20 * bounded, (bounded, exploding)          # 13 fusion steps at weight 2 on the overlap

@@ -5,6 +5,8 @@ Tolerances: kernels read bf16 operands and accumulate in fp32; outputs are round
 |err| <= 2 bf16 ulp of the result (rtol 2^-7) plus an absolute term for cancellation.
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -12,6 +14,26 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 BF = torch.bfloat16
+
+
+@pytest.fixture
+def lib_env():
+    """set one of the library's environment switches mid-process.  The library reads them once per process (a launch and the query that accounts for it must agree);
+    tmix_env_refresh() re-reads them.  Restored on teardown."""
+    from tweediemix_amd import lib as L
+    saved = {}
+
+    def set_(name, value="1"):
+        saved.setdefault(name, os.environ.get(name))
+        os.environ[name] = value
+        L.load().tmix_env_refresh()
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    L.load().tmix_env_refresh()
 
 
 @pytest.fixture(scope="module")
@@ -255,7 +277,7 @@ def test_gemm_batched_weights_and_transposed_out(ops, cfg):
 
 
 @pytest.mark.parametrize("cfg", [1, 2, 4, 6, 7, 13, 14, 16, 17, 18, 21, 22])
-def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch):
+def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch, lib_env):
     """the LDS-staged 16-byte stores (default) against the accumulator-layout 8-byte stores (TMIX_NARROW_EPILOGUE=1, the
     fallback for unaligned rows): same values, same operation order per element => identical C, GEGLU output and V^T; the
     row statistics are summed in a different (fixed) order, so they agree to fp32 rounding only."""
@@ -279,7 +301,7 @@ def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch)
         torch.cuda.synchronize()
         return c, c2, g, vt, qk, f32, st
     wide = run()
-    monkeypatch.setenv("TMIX_NARROW_EPILOGUE", "1")
+    lib_env("TMIX_NARROW_EPILOGUE")
     narrow = run()
     for x, y, name in zip(wide[:6], narrow[:6], ("C", "C+stats", "GEGLU", "Vt", "QK", "f32")):
         assert torch.equal(x, y), name
@@ -291,7 +313,7 @@ def test_wide_epilogue_is_bit_identical_to_the_narrow_one(ops, cfg, monkeypatch)
 
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 1, 64, 1), (2, 3, 1000, 77), (1, 2, 70, 96), (2, 2, 300, 33), (1, 20, 1024, 77),
                                           (4, 20, 1024, 77), (2, 9, 4096, 77)])     # the last two: five-wave workgroups (the very last with surplus waves)
-def test_short_key_attention_kernel_matches_the_general_one(ops, B, H, Sq, Skv, monkeypatch):
+def test_short_key_attention_kernel_matches_the_general_one(ops, B, H, Sq, Skv, monkeypatch, lib_env):
     """attn_small_kernel (K / V^T register-resident, exact softmax; Skv <= 96) vs torch and vs the tiled flash kernel
     (TMIX_ATTN_GENERAL=1) on the same inputs, incl. ragged query counts and a single key."""
     Cc = H * 64
@@ -300,7 +322,7 @@ def test_short_key_attention_kernel_matches_the_general_one(ops, B, H, Sq, Skv, 
     vt = torch.zeros(B, Cc, ld, device="cuda", dtype=BF)
     vt[:, :, :Skv] = v.transpose(1, 2)
     small = ops.attention(q, k, vt, H, Skv, 0.125)
-    monkeypatch.setenv("TMIX_ATTN_GENERAL", "1")
+    lib_env("TMIX_ATTN_GENERAL")
     general = ops.attention(q, k, vt, H, Skv, 0.125)
 
     def heads(t):
@@ -496,7 +518,7 @@ def test_attention_key_split_applies_to_partly_filled_last_rounds_only(ops):
 # --------------------------------------------------------------------------- norms / small ops
 @pytest.mark.parametrize("B,HW,C1,C2,silu", [(32, 336, 1280, 0, True), (32, 84, 1280, 0, False), (32, 336, 1280, 640, True), (8, 1344, 320, 0, True),
                                              (3, 84, 640, 320, True), (2, 1024, 320, 320, False), (1, 100, 64, 0, True)])
-def test_groupnorm_of_small_images_in_one_launch(ops, monkeypatch, B, HW, C1, C2, silu):
+def test_groupnorm_of_small_images_in_one_launch(ops, monkeypatch, B, HW, C1, C2, silu, lib_env):
     """tmix_groupnorm_nhwc on images whose (HW x channels of a few groups) slice is small runs statistics + apply in ONE launch, one workgroup per (image, group set)
     (the video UNet's 336- / 84-pixel frames).  Against torch, against the three-launch form (TMIX_GN_NO_SMALL=1: same statistics up to fp32 summation order), and
     batch-independent: an image's bits do not depend on how many images share the launch."""
@@ -512,7 +534,7 @@ def test_groupnorm_of_small_images_in_one_launch(ops, monkeypatch, B, HW, C1, C2
     close(y, ref.transpose(1, 2), rtol=2 ** -6, atol_frac=4e-3)
     y1 = ops.groupnorm(x1[:1].contiguous(), g, b, 32, 1e-5, silu, x2=None if x2 is None else x2[:1].contiguous())
     assert torch.equal(y1, y[:1])
-    monkeypatch.setenv("TMIX_GN_NO_SMALL", "1")
+    lib_env("TMIX_GN_NO_SMALL")
     y3 = ops.groupnorm(x1, g, b, 32, 1e-5, silu, x2=x2)
     torch.cuda.synchronize()
     d = (y.float() - y3.float()).abs()
@@ -1271,6 +1293,12 @@ def test_gemm_w22_bias_residual_statistics_and_folded_layernorm(ops, M, N, K, ba
     close(y, F.layer_norm(hf, (N,), gamma, beta, 1e-5) @ w2.float().T + b2, rtol=2 ** -6, atol_frac=4e-3)
 
 
+_EXPERIMENTAL = pytest.mark.skipif(not os.environ.get("TMIX_EXPERIMENTAL_TILINGS"),
+                                   reason="tilings 24 / 25 live in dev variants only (tools/build_variant.sh x EXPERIMENTAL=1; run with TMIX_LIB=<variant> TMIX_EXPERIMENTAL_TILINGS=1): "
+                                          "the shipped library runs those ids as tilings 14 / 23")
+
+
+@_EXPERIMENTAL
 @pytest.mark.parametrize("M,N,K,batch", [(4096, 1280, 5120, 1), (1024, 1280, 1280, 4), (300, 640, 2560, 1), (129, 320, 192, 3), (128, 160, 64, 1)])
 def test_gemm_w22_with_l2_prefetcher_wave_equals_tiling_23_bit_for_bit(ops, M, N, K, batch):
     """tiling 25 = tiling 23's math waves behind three DMA loaders and one prefetcher wave: the same bits, whatever the K depth (1 to 80 K-tiles)"""
@@ -1391,6 +1419,7 @@ def test_long_row_quantiser_fallback_uses_the_kernels_scale_arithmetic(ops):
 
 
 # --------------------------------------------------------------------------- tiling 24 (gemm_ff1p.hip): 256 x 320 on persistent workgroups
+@_EXPERIMENTAL
 @pytest.mark.parametrize("M,N,K,ln", [(4096, 10240, 1280, True), (16384, 5120, 640, True), (2048, 10240, 1280, True), (256, 320, 128, False), (768, 960, 192, True), (512, 20480, 64 * 3, False)])
 def test_gemm_persistent_geglu_equals_tiling_14_bit_for_bit(ops, M, N, K, ln):
     """the FF up-projection on persistent workgroups (one per CU walking 1, 2, 4 ... tiles: 512 / 1024 / 256 tiles at the SDXL shapes, and grids smaller

@@ -371,6 +371,12 @@ def test_bench_line_contract(tmp_path):
     rf, cb = d["roofline"], d["cpu_baseline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "traffic" in rf
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # round 6: the headline is timed on masks that partition the image; the same window on the intersecting rectangles of rounds 1-5 and the window right
+    # behind the plan build travel in `config` (the driver's record keeps that object), and the line says where `roofline.traffic` comes from
+    cfgd = d["config"]
+    assert cfgd["masks"].startswith("partition") and cfgd["first_window_ms_per_step"] > 0 and cfgd["other_mask_kind_ms_per_step"] > 0
+    assert d["other_mask_kind_window"]["masks"] == "overlap" and d["max_abs_latent_at_end_of_window"] < 1e3
+    assert "profiles/MANIFEST.json" in rf["traffic_source"]
 
 
 def test_bench_two_ranks_control_flow(tmp_path):

@@ -455,6 +455,31 @@ def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, call_kind, n_seeds, 
           f"max_rel={worst[1]:.4g} tilings={U.used_tilings(plan)}")
 
 
+def test_plain_plan_co_batched_rows_equal_the_single_seed_call_at_sdxl_size(sdxl_weights, monkeypatch):
+    """whether attn2 runs as ONE launch (tmix_gemm_q_cross_attn: q rounded after scale * log2e, its own softmax) or as the to_q GEMM +
+    attention pair must be a function of the image's shape only -- never of the batch -- or a co-batched seed stops matching its single-seed run.
+    The B = 2 `plain` call at latent 128 x 128 (the 32 x 32 level's 64 tiles per image) against the same rows co-batched 2 x (B = 4), ONE tiling
+    everywhere (TMIX_FORCE_TILE: the tuner's per-shape choices add LayerNorm partials in different orders): the same kernels per layer, and eps of
+    the first seed's rows equal bit for bit.  Call sites: fusion_sampling.py:360-374,406,440."""
+    monkeypatch.setenv("TMIX_FORCE_TILE", "1")
+    hw = 128
+    one, ehs, pooled, tid, _con = _timed_plan(sdxl_weights, "lora", hw, 1, call_kind="plain", n_seeds=1)
+    two, _e, _p, _t, _c = _timed_plan(sdxl_weights, "lora", hw, 1, call_kind="plain", n_seeds=2)
+    assert one.B == 2 and two.B == 4
+
+    def names(plan):
+        return [getattr(fn, "__name__", "") for fn, _a in plan.ops if getattr(fn, "__name__", "") != "tmix_gemm_prefetch_next"]
+    assert names(one) == names(two), "the launch list of a call must not depend on how many seeds share it"
+    assert names(one).count("tmix_gemm_q_cross_attn") == 70
+    g = torch.Generator().manual_seed(6)
+    xs = torch.randn(2, 1, 4, hw, hw, generator=g)
+    x2 = xs.repeat(1, 2, 1, 1, 1).reshape(4, 4, hw, hw).cuda()
+    e1 = one(x2[:2], 601).clone()
+    e2 = two(x2, 601).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(e1).all() and torch.equal(e1, e2[:2]), float((e1 - e2[:2]).abs().max())
+
+
 def test_low_rank_lora_full_size_sdxl_vs_oracle(sdxl_weights):
     """`--lora_mode lowrank` at the REAL SDXL widths (2.57 B parameters, 280 routed projections each behind a tmix_lora_down launch,
     shared weights over K + 64 columns), latent 64 x 64, B = 4 concept-routed rows, the sampler's own plan builder, hipGraph replay,

@@ -600,9 +600,20 @@ __global__ void __launch_bounds__(320, 2) attn_small_kernel(const AttnParams p) 
 // Key-split tail: B * H * ceil(Sq / 128) items on 512 workgroup slots (two per CU).  When a last, partly filled round remains (SDXL: 640 items at S = 1024,
 // 1280 at S = 4096) its r items are cut into 512 / r key ranges, one workgroup each, so that the last round is 1 / split as long and fills every slot.
 struct AttnSplit { int n_full, lsplit, tpp, n_tail; int64_t ws_bytes; };
+// (SLOTS and the tail's tile -> XCD mapping -- j >> 3, j & 7 in the kernel -- are the MI355X's: 256 CUs x 2 resident workgroups, 8 XCDs.  On a part with another CU
+// count "all ranges of an item on one XCD" and "the split fills the last round" no longer hold, so the split switches itself off there; the library refuses non-gfx950
+// devices anyway, tmix_check_device.  Asked at launch time: tmix_attn_split_ws_bytes is a pure function of the shape.)
+static bool attn_split_device_ok() {
+    static int ok = -1;
+    if (ok < 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount * 2 == 512) ? 1 : 0;
+    }
+    return ok == 1;
+}
 static bool attn_split_plan(int B, int H, int Sq, int Skv, AttnSplit& sp) {
     constexpr int SLOTS = 512, TICKET_BYTES = 4096;
-    if (Skv <= SK_MAX || (Skv % KB) || getenv("TMIX_ATTN_NO_SPLIT")) return false;
+    if (Skv <= SK_MAX || (Skv % KB) || tmix_env(TMIX_ENV_ATTN_NO_SPLIT)) return false;
     const int64_t items = (int64_t)((Sq + QB - 1) / QB) * B * H;
     const int nt = Skv / KB;
     const int r = (int)(items % SLOTS);
@@ -653,7 +664,7 @@ static int attn_entry(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.nq = (Sq + QB - 1) / QB;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.prof = tmix_prof_take(&p.prof_detail);
-    if (Skv <= SK_MAX && !getenv("TMIX_ATTN_GENERAL")) {          // short key set: K / V^T resident in registers, no LDS
+    if (Skv <= SK_MAX && !tmix_env(TMIX_ENV_ATTN_GENERAL)) {          // short key set: K / V^T resident in registers, no LDS
         p.nq = (Sq + SQW - 1) / SQW;
         const int64_t waves = (int64_t)p.nq * B * H;
         // workgroups of five waves when that fills whole rounds of 256 CUs better than four (waves / CU rounded up, then fewer workgroups)
@@ -670,7 +681,7 @@ static int attn_entry(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     if (nwg > 0x7fffffff) TMIX_FAIL(TMIX_ESHAPE, "attn: grid too large");
     p.n_full = (int)nwg; p.lsplit = 0; p.tpp = 0; p.ws = nullptr; p.tickets = nullptr;
     AttnSplit sp;
-    if (ws && attn_split_plan(B, H, Sq, Skv, sp)) {
+    if (ws && attn_split_device_ok() && attn_split_plan(B, H, Sq, Skv, sp)) {     // (the size query stays a pure function of the shape; the device is asked here)
         if ((((uintptr_t)ws) & 15) || ws_bytes < sp.ws_bytes)
             TMIX_FAIL(TMIX_EINVAL, "attn: the key-split workspace needs %lld bytes (tmix_attn_split_ws_bytes), 16-byte aligned; got %lld", (long long)sp.ws_bytes, (long long)ws_bytes);
         p.n_full = sp.n_full; p.lsplit = sp.lsplit; p.tpp = sp.tpp;
@@ -678,6 +689,14 @@ static int attn_entry(const void* Q, int64_t ldq, int64_t strideQ, const void* K
         nwg = (int64_t)sp.n_full + ((int64_t)sp.n_tail << sp.lsplit);
     }
     attn_fwd_pipe_kernel<<<dim3((unsigned)nwg), 256, SMEM_P, (hipStream_t)stream>>>(p);
+    if (p.tickets) {      // a launch that did not start leaves no one to reset the tickets: re-zero them (best effort), or every later launch on this workspace would never merge
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) {
+            (void)hipMemsetAsync(p.tickets, 0, 4096, (hipStream_t)stream);
+            TMIX_FAIL((int)e_, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_));
+        }
+        return TMIX_OK;
+    }
     TMIX_LAUNCH_CHECK();
     return TMIX_OK;
 }

@@ -1,5 +1,6 @@
 // capi.cpp -- version / error plumbing of the C ABI (include/tmix.h)
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -36,6 +37,18 @@ extern "C" int tmix_gemm_prefetch_next(const void* next_weights, int64_t bytes, 
     g_pf_ptr = (next_weights && bytes > 0) ? (const char*)next_weights : nullptr;
     g_pf_bytes = g_pf_ptr ? bytes : 0;
     return TMIX_OK;
+}
+
+static const char* const g_env_names[TMIX_ENV_COUNT] = {"TMIX_GN_NO_SMALL", "TMIX_ATTN_NO_SPLIT", "TMIX_ATTN_GENERAL", "TMIX_NARROW_EPILOGUE"};
+static int g_env[TMIX_ENV_COUNT];
+static bool g_env_read = false;     // (racing first users read the same environment and store the same values)
+extern "C" void tmix_env_refresh(void) {
+    for (int i = 0; i < TMIX_ENV_COUNT; ++i) g_env[i] = getenv(g_env_names[i]) != nullptr;
+    g_env_read = true;
+}
+bool tmix_env(int which) {
+    if (!g_env_read) tmix_env_refresh();
+    return g_env[which] != 0;
 }
 
 extern "C" int tmix_version(void) { return TMIX_VERSION; }

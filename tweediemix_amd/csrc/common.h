@@ -62,6 +62,11 @@ __device__ __forceinline__ float exp2_neg_int(int e) { return e >= 127 ? __uint_
 
 // thread-local error string (host side)
 void tmix_set_error(const char* fmt, ...);
+
+// The library's environment switches (debug / A-B knobs).  Read ONCE per process, on first use: a launch, the *_launches / *_ws_bytes query that accounts for it and a
+// captured graph must all see the same value, and an eager launch does not scan the environment.  tmix_env_refresh() re-reads them (tests flip a switch mid-process).
+enum { TMIX_ENV_GN_NO_SMALL = 0, TMIX_ENV_ATTN_NO_SPLIT, TMIX_ENV_ATTN_GENERAL, TMIX_ENV_NARROW_EPILOGUE, TMIX_ENV_COUNT };
+bool tmix_env(int which);
 #define TMIX_FAIL(code, ...) do { tmix_set_error(__VA_ARGS__); return (code); } while (0)
 #define TMIX_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     tmix_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)

@@ -19,9 +19,13 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
     if (cfg == 8) cfg = 19; else if (cfg == 9) cfg = 2; else if (cfg == 10) cfg = 1; else if (cfg == 11) cfg = 4;   // round-1 loader-wave tilings, retired (3 waves / SIMD register budget: they spilled)
     // 23 = 128x160 over 2 x 2 math waves of 64x80 (v_mfma_f32_16x16x32_bf16) + four loader waves (gemm_w22.hip): the staged plain bf16 epilogue only
+#ifdef TMIX_EXPERIMENTAL_TILINGS      // dev variants (make EXPERIMENTAL=1): 24 = 256x320 on persistent workgroups (gemm_ff1p.hip), 25 = tiling 23 with an L2 prefetcher wave
     if (cfg == 23 || cfg == 25) { if (w22_eligible(p, conv, 0)) return launch_w22(p, batch, st, cfg == 25); cfg = conv ? 12 : 21; }
-    // 24 = 256x320 on persistent workgroups (gemm_ff1p.hip): the staged GEGLU epilogue on whole tiles, shared weights; anything else runs as tiling 14
     if (cfg == 24) { if (ff1p_eligible(p, conv, 0, batch)) return launch_ff1p(p, st); cfg = 14; }
+#else                                 // the shipped library: ids 24 / 25 are reserved and run as the tilings they were variants of (same bits)
+    if (cfg == 24) cfg = 14; else if (cfg == 25) cfg = 23;
+    if (cfg == 23) { if (w22_eligible(p, conv, 0)) return launch_w22(p, batch, st, 0); cfg = conv ? 12 : 21; }
+#endif
     if (cfg == 6) cfg = 4;      // 256x256 over four waves (128x128 wave tiles) is retired: it spilled and lost everywhere; same tile shape over eight waves
     if (p.n_trans_begin >= 0) {
         int bm = 0, bn = 0;
@@ -184,7 +188,7 @@ static int gemm_entry(const tmix_gemm_desc* d, bool fp8, const uint8_t* scaleA, 
     const bool c16 = d->C && aligned16(d->C) && (d->ldc % 8) == 0 && (d->strideC % 8) == 0;
     const bool r16 = !d->residual || (aligned16(d->residual) && (d->ldr % 8) == 0 && (d->strideR % 8) == 0);
     p.wide = 0;
-    if (!getenv("TMIX_NARROW_EPILOGUE")) {
+    if (!tmix_env(TMIX_ENV_NARROW_EPILOGUE)) {
         if (d->epilogue == TMIX_EPI_GEGLU) { if (c16 || p.f8out) p.wide |= 2; }
         else if (d->epilogue == TMIX_EPI_F32OUT) { if (aligned16(d->C) && (d->ldc % 4) == 0 && (d->strideC % 4) == 0 && (d->N % 8) == 0) p.wide |= 1; }
         else if (c16 && r16 && (d->N % 8) == 0) p.wide |= 1;
@@ -266,7 +270,7 @@ static int conv_entry(const tmix_conv_desc* d, const uint8_t* scale_x, const uin
     p.bytesA = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * (fp8 ? 1 : 2));
     p.bytesW = (unsigned)((int64_t)d->Cout * p.K * (fp8 ? 1 : 2));
     if (fp8) { p.scaleA = scale_x; p.scaleW = scale_w; p.ldScaleA = d->Cin / 32; }
-    p.wide = (!getenv("TMIX_NARROW_EPILOGUE") && aligned16(d->Y) && (d->Cout % 8) == 0 && (!d->residual || aligned16(d->residual))) ? 1 : 0;
+    p.wide = (!tmix_env(TMIX_ENV_NARROW_EPILOGUE) && aligned16(d->Y) && (d->Cout % 8) == 0 && (!d->residual || aligned16(d->residual))) ? 1 : 0;
     if (p.S1 && !p.wide) TMIX_FAIL(TMIX_EALIGN, "conv3x3: shortcut taps need the staged epilogue (16-byte aligned Y, Cout %% 8 == 0)");
     if (d->col_stats_out) {
         if ((M % TMIX_COLSTATS_ROWS) || !aligned16(d->col_stats_out) || !p.wide)

@@ -1599,6 +1599,8 @@ int launch_cfg(Params& p, int batch, hipStream_t st) {
     p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
     p.group_m = BM >= 256 ? 4 : 8;
     if (BM >= 256 && BN >= 256) p.group_m = 8;
+    // the kernels remap the LINEAR workgroup id over the whole (tiles, slices) grid in 32-bit arithmetic (common.h xcd_remap_grid)
+    if ((int64_t)p.tiles_m * p.tiles_n * batch > 0x7fffffffLL) TMIX_FAIL(TMIX_ESHAPE, "gemm: %lld x %d workgroups exceed the 32-bit linear grid id", (long long)p.tiles_m * p.tiles_n, batch);
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     p.prof = tmix_prof_take(&p.prof_detail);
     tmix_prefetch_take(&p.pf, &p.pf_bytes);

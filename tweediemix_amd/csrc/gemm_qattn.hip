@@ -408,6 +408,8 @@ int launch_qattn(Params& p, const QAExtra& x, int batch, hipStream_t st) {
     QAParams q;
     p.tiles_m = (p.M + Q_BM - 1) / Q_BM; p.tiles_n = p.N / Q_BN;
     p.group_m = 16;
+    // the kernels remap the LINEAR workgroup id over the whole (tiles, slices) grid in 32-bit arithmetic (common.h xcd_remap_grid)
+    if ((int64_t)p.tiles_m * p.tiles_n * batch > 0x7fffffffLL) TMIX_FAIL(TMIX_ESHAPE, "gemm: %lld x %d workgroups exceed the 32-bit linear grid id", (long long)p.tiles_m * p.tiles_n, batch);
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     p.prof = tmix_prof_take(&p.prof_detail);
     tmix_prefetch_take(&p.pf, &p.pf_bytes);

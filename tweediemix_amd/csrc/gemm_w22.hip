@@ -380,6 +380,8 @@ template <int PFW> static int launch_w22_t(Params& p, int batch, hipStream_t st)
     }
     p.tiles_m = (p.M + W_BM - 1) / W_BM; p.tiles_n = (p.N + W_BN - 1) / W_BN;
     p.group_m = 8;
+    // the kernels remap the LINEAR workgroup id over the whole (tiles, slices) grid in 32-bit arithmetic (common.h xcd_remap_grid)
+    if ((int64_t)p.tiles_m * p.tiles_n * batch > 0x7fffffffLL) TMIX_FAIL(TMIX_ESHAPE, "gemm: %lld x %d workgroups exceed the 32-bit linear grid id", (long long)p.tiles_m * p.tiles_n, batch);
     dim3 grid(p.tiles_m * p.tiles_n, batch, 1);
     p.prof = tmix_prof_take(&p.prof_detail);
     tmix_prefetch_take(&p.pf, &p.pf_bytes);
@@ -390,6 +392,10 @@ template <int PFW> static int launch_w22_t(Params& p, int batch, hipStream_t st)
     return TMIX_OK;
 }
 
+#ifdef TMIX_EXPERIMENTAL_TILINGS
 int launch_w22(Params& p, int batch, hipStream_t st, int l2_prefetcher) { return l2_prefetcher ? launch_w22_t<1>(p, batch, st) : launch_w22_t<0>(p, batch, st); }
+#else       // the prefetcher-wave form (tiling 25: 50 % slower) is compiled into dev variants only
+int launch_w22(Params& p, int batch, hipStream_t st, int) { return launch_w22_t<0>(p, batch, st); }
+#endif
 
 }  // namespace tmix_gemm

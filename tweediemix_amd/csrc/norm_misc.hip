@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256) gn_small_kernel(const bf16_t* __restrict_
 // gpw for the one-launch form, or 0 when the shape does not qualify (the slice must be small).  A function of the image's shape ONLY -- not of the batch: co-batched seeds
 // and row-split chains must take the same path as a single run to reproduce it bit for bit.
 static int gn_small_gpw(int64_t HW, int C, int groups) {
-    if (getenv("TMIX_GN_NO_SMALL")) return 0;
+    if (tmix_env(TMIX_ENV_GN_NO_SMALL)) return 0;
     const int cpg = C / groups;
     for (int gpw = 1; gpw <= 8; gpw <<= 1) {
         if (groups % gpw || ((gpw * cpg) & 7)) continue;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tmix_version": (C.c_int, []),
     "tmix_last_error_string": (C.c_char_p, []),
     "tmix_check_device": (C.c_int, []),
+    "tmix_env_refresh": (None, []),
     "tmix_prof_begin": (C.c_int, [vp, C.c_int, C.c_int]),
     "tmix_prof_end": (C.c_int, []),
     "tmix_fused_tweedie_step": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, i64, C.c_int,

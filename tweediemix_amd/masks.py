@@ -49,6 +49,44 @@ def random_rectangle_masks(K: int, H: int, W: int, seed: int = 0):
     return out
 
 
+def partition_rectangle_masks(K: int, H: int, W: int, seed: int = 0):
+    """K-1 seeded rectangles that do NOT overlap: rectangle k loses every pixel an earlier one claimed (what the side-car's
+    overlap rule does to its second mask above the 0.8 threshold, text_segment/run_expand.py:78-87), re-drawn while less than
+    half of it survives.  With these, fg_1 + ... + fg_{K-1} + bg == 1 on every pixel, i.e. the blend of
+    fusion_sampling.py:466-469 is a convex combination and the latent keeps its scale through the fusion window; with
+    random_rectangle_masks the weights sum to 2 on the overlap and that region doubles every fusion step (the reference does
+    not normalise).  uint8 {0,255}, same conventions as random_rectangle_masks."""
+    rng = np.random.RandomState(seed)
+    taken = np.zeros((H, W), bool)
+    out = []
+    for _ in range(K - 1):
+        for _try in range(64):
+            area = rng.uniform(0.10, 0.30) * H * W
+            ar = rng.uniform(0.6, 1.6)
+            hh = int(min(H, max(8, round((area * ar) ** 0.5))))
+            ww = int(min(W, max(8, round(area / hh))))
+            y0 = rng.randint(0, H - hh + 1)
+            x0 = rng.randint(0, W - ww + 1)
+            m = np.zeros((H, W), bool)
+            m[y0:y0 + hh, x0:x0 + ww] = True
+            m &= ~taken
+            if 2 * int(m.sum()) >= hh * ww:
+                break
+        taken |= m
+        out.append(m.astype(np.uint8) * 255)
+    return out
+
+
+def synthetic_masks(kind: str, K: int, H: int, W: int, seed: int = 0):
+    """'partition' (default of bench.py and the trajectory parity test) or 'overlap' (random_rectangle_masks: the reference's
+    un-normalised weights on intersecting rectangles, kept as a labelled second case)."""
+    if kind == "partition":
+        return partition_rectangle_masks(K, H, W, seed)
+    if kind == "overlap":
+        return random_rectangle_masks(K, H, W, seed)
+    raise ValueError(f"mask kind {kind!r}: 'partition' or 'overlap'")
+
+
 def expand_masks(masks):
     """The side-car's post-processing of the two SAM masks (text_segment/run_expand.py:35-87): every mask becomes its
     bounding rectangle; where the two rectangles overlap, the bounding box of the overlap is re-filled with the

@@ -945,8 +945,11 @@ class UNetPlan:
                 self._proj(ao, a1 + ".out", h, S, Cc, bias=W[a1 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao_full)
                 A.put(ao_full)
             # --- cross attention against the cached K / V^T; norm2 folded into to_q
-            # (one launch only where its 64 x 320 tiles fill the chip: the B = 2 calls at the 32 x 32 level are 128 tiles -- 24.2 vs 23.1 us for the two launches)
-            if getattr(self, "_qattn", False) and Cc % 320 == 0 and S % 64 == 0 and (B * S // 64) * (Cc // 320) >= 200:
+            # The choice is a function of the IMAGE's shape only, never of the batch (like gn_small_gpw): the one-launch form rounds q and runs its softmax
+            # differently from the pair, so a batch-dependent choice would make a co-batched seed differ from its single-seed run.  64 tiles of
+            # 64 x 320 per image = the 1024^2 latent's 32 x 32 level; the B = 2 calls there fill half the chip (128 tiles: 24.2 us against 23.1 + a kernel
+            # boundary for the pair), smaller images (512^2: 32 / 16 tiles per image) keep the pair at every batch.
+            if getattr(self, "_qattn", False) and Cc % 320 == 0 and S % 64 == 0 and (S // 64) * (Cc // 320) >= 64:
                 ao = A.get(B, S, Cc)
                 self._q_attn(h, a2 + ".q", self.kv.k[a2], self.kv.vt[a2], ao, S, Cc, st)
                 self._proj(ao, a2 + ".out", h, S, Cc, bias=W[a2 + ".to_out.0.bias"], residual=h, stats_out=st, f8_copy=h8, a_full=ao)
