@@ -128,7 +128,10 @@ enum { TMIX_TILE_AUTO = 0, TMIX_TILE_128x128_S2 = 1, TMIX_TILE_256x128_S3 = 2, T
                                       plain staged bf16 epilogue (bias, folded LayerNorm, residual, row statistics) -- other launches run as tiling 21 */,
        /* ids 24 and 25 are RESERVED: two measured-and-rejected experiments (256x320 on persistent workgroups; tiling 23 with an L2 prefetcher wave) that only dev
           builds contain (make EXPERIMENTAL=1, tools/build_variant.sh); the shipped library runs them as tilings 14 and 23, whose bits they reproduce */
-       TMIX_TILE_COUNT = 25 };
+       TMIX_TILE_CONV_HALO = 26 /* tmix_conv3x3_nhwc only: stride-1 3x3 convolution on 4 x 32 pixel tiles with the (4 + 2) x (32 + 2) input patch of every 64-channel chunk resident
+                                   in LDS -- the nine taps are shifted fragment reads, the input travels L2 -> LDS 1.6 x instead of 9 x.  W %% 32 == 0, H %% 4 == 0, Cout %% 160 == 0, no shortcut
+                                   taps; other launches run as tiling 20 (a GEMM: 21).  Channel-chunk-major accumulation order (the other tilings: tap-major) */,
+       TMIX_TILE_COUNT = 26 };
 typedef struct {
     const void* A;  int64_t lda, strideA;        /* bf16 [batch][M][lda]                          */
     const void* W;  int64_t ldw, strideW;        /* bf16 [batch|1][N][ldw]                        */

@@ -86,9 +86,10 @@ def test_argument_errors_are_reported_before_any_launch():
         assert l.tmix_gemm_tile_shape(cfg, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (128, 160)
     assert l.tmix_gemm_tile_shape(22, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (256, 320)       # 256 x 320, phase-offset loop
     assert l.tmix_gemm_tile_shape(23, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (128, 160)       # 2 x 2 waves of 64 x 80
-    assert l.tmix_gemm_tile_shape(24, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (256, 320)       # persistent 256 x 320
-    assert l.tmix_gemm_tile_shape(25, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (128, 160)       # 23 + L2 prefetcher wave
-    assert l.tmix_gemm_tile_shape(26, C.byref(bm), C.byref(bn)) < 0 and l.tmix_gemm_stats_parts(1280, 14) == 4
+    assert l.tmix_gemm_tile_shape(24, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (256, 320)       # (reserved id: dev builds run 256 x 320 on persistent workgroups, the shipped library tiling 14)
+    assert l.tmix_gemm_tile_shape(25, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (128, 160)       # (reserved id: dev builds add an L2 prefetcher wave to tiling 23)
+    assert l.tmix_gemm_tile_shape(26, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == (128, 160)       # halo-patch convolution: 4 x 32 pixels x 160 channels
+    assert l.tmix_gemm_tile_shape(27, C.byref(bm), C.byref(bn)) < 0 and l.tmix_gemm_stats_parts(1280, 14) == 4
     # the whole-step entry points and the timing hook validate before touching the device
     assert l.tmix_step_prologue(fake, fake, fake, fake, 1, 4, 6, None) < 0            # n % 4
     assert l.tmix_fused_tweedie_step_dev(fake, fake, 0, None, 0, fake, None, 3, 4, 64, 0, 4, 1, fake, None) < 0   # FUSION without masks

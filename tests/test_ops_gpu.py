@@ -625,6 +625,52 @@ def test_conv_with_shortcut_taps(ops, cfg, B, H, W, Cin, Cout, c1, c2, cs):
         _colstats_close(csb, out)
 
 
+# --------------------------------------------------------------------------- tiling 26 (gemm_convh.hip): the input halo patch resident in LDS
+@pytest.mark.parametrize("B,H,W,Cin,Cout,extra", [(1, 4, 32, 64, 160, ""), (2, 8, 32, 128, 320, "trc"), (1, 32, 32, 1280, 1280, "rc"), (3, 12, 64, 192, 160, "t"),
+                                                  (2, 64, 64, 320, 640, "tc"), (4, 128, 128, 320, 320, "trc"), (1, 16, 96, 64, 480, "r")])
+def test_conv3x3_with_the_halo_patch_in_lds(ops, B, H, W, Cin, Cout, extra):
+    """TMIX_TILE_CONV_HALO: 4 x 32 pixel tiles, channel-chunk-major K loop, the nine taps as shifted fragment reads of ONE (4 + 2) x (32 + 2) patch per 64-channel chunk.
+    Against F.conv2d (image borders = the patch's zero padding, tile borders inside the image = real neighbours, several images, 1 .. 20 chunks), with the time-embedding
+    row, the residual and the GroupNorm column statistics of the ResnetBlock2D launches; and against tiling 20 (same products, tap-major order: equal to fp32 rounding)."""
+    from tweediemix_amd import lib as L
+    x = rnd(B, H, W, Cin, seed=500)
+    w = rnd(Cout, 3, 3, Cin, seed=501, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=502, dtype=torch.float32)
+    temb = rnd(B, Cout, seed=503, dtype=torch.float32) if "t" in extra else None
+    res = rnd(B, H, W, Cout, seed=504) if "r" in extra else None
+    cs = ops.colstats_buf(B * H * W, Cout, "cuda") if "c" in extra else None
+    if cs is not None:
+        cs.fill_(float("nan"))
+    out = ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=res, tile_cfg=L.TILE_CONV_HALO, col_stats_out=cs)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    if temb is not None:
+        ref = ref + temb[:, None, None, :]
+    if res is not None:
+        ref = ref + res.float()
+    close(out, ref)
+    other = ops.conv3x3(x, w, bias=bias, batch_bias=temb, residual=res, tile_cfg=20)
+    d = (out.float() - other.float()).abs().max().item()
+    assert d <= 2 ** -7 * max(1.0, ref.abs().max().item()), d            # one bf16 ulp of the largest output: the two differ by the fp32 summation order only
+    if cs is not None:
+        _colstats_close(cs, out)
+
+
+def test_halo_conv_falls_back_for_launches_it_does_not_carry(ops):
+    """stride 2, nearest x2, shortcut taps, a width that is not a multiple of 32 or of 160 output channels run as tiling 20: the same bits as asking for it"""
+    from tweediemix_amd import lib as L
+    x = rnd(2, 16, 16, 64, seed=510)
+    w = rnd(160, 3, 3, 64, seed=511, scale=(9 * 64) ** -0.5)
+    for mode in (0, 1, 2):                                  # W = 16: not a multiple of 32
+        assert torch.equal(ops.conv3x3(x, w, mode=mode, tile_cfg=L.TILE_CONV_HALO), ops.conv3x3(x, w, mode=mode, tile_cfg=20))
+    x2 = rnd(1, 8, 32, 64, seed=512)
+    w2 = rnd(128, 3, 3, 64, seed=513, scale=(9 * 64) ** -0.5)      # Cout = 128
+    assert torch.equal(ops.conv3x3(x2, w2, tile_cfg=L.TILE_CONV_HALO), ops.conv3x3(x2, w2, tile_cfg=20))
+    wsc = rnd(160, 64, seed=514, scale=64 ** -0.5)
+    x1 = rnd(1, 8, 32, 64, seed=515)
+    assert torch.equal(ops.conv3x3(x2, ops.shortcut_weight(w, wsc), tile_cfg=L.TILE_CONV_HALO, shortcut=(x1, None)),
+                       ops.conv3x3(x2, ops.shortcut_weight(w, wsc), tile_cfg=20, shortcut=(x1, None)))
+
+
 def test_column_statistics_reject_what_they_cannot_serve(ops):
     from tweediemix_amd import lib as L
     a, w = rnd(128, 64), rnd(128, 64)

@@ -17,14 +17,22 @@ from trajectory_parity import trajectory_parity
 
 pytestmark = pytest.mark.gpu
 
-# stated tolerance, against the fp32 oracle trajectory on identical weights, partition masks:
+# stated tolerance, against the fp32 oracle trajectory on identical weights, partition masks.
+# measured (MI355X, round 6, 512^2 n = 20; bf16 LoRA | fp8 LoRA | bf16 Custom-Diffusion):
+#   eps per call, oracle's latent      3.6e-3 (4.5e-3 at the start step) | 3.6e-3 (5.0e-3) | 3.6e-3 (4.5e-3)     -- the same at every one of the 20 steps
+#   x' per step, oracle's latent       3.3e-3 falling to 7e-5 (the update shrinks from 21 % to 1.2 % of x') | 3.6e-3 | 3.3e-3;   start step 3.3e-2 | 4.0e-2 | 3.3e-2
+#   error / update per step            1.6e-2 ... 2.2e-2 | 1.7e-2 ... 2.2e-2 | 1.6e-2 ... 2.2e-2                   -- fusion window included (2.2e-2 is inside it)
+#   eps per call, free-running         3.2e-2 ... 3.7e-2 | 3.9e-2 ... 4.4e-2 | 3.2e-2 ... 3.7e-2                   -- the start step's drift, carried
+#   final latent, free-running         3.8e-2 | 4.6e-2 | 3.8e-2;   max|x| along the trajectory 38.6 (x_T: 4.2)
 TOL_EPS_CALL = 2e-2        # eps of one UNet call on the oracle's own latent (the per-call bound of every whole-UNet test), every scheduler step
 TOL_STEP = 1e-2            # rel L2 of x' after one scheduler step started from the oracle's latent (one UNet call + the exact fused step)
-TOL_STEP_UPDATE = 3e-2     # the same error over the step's UPDATE ||x' - sqrt(a'/a) x|| (the part of x' that eps produced)
+TOL_STEP_UPDATE = 4e-2     # the same error over the step's UPDATE ||x' - sqrt(a'/a) x|| (the part of x' that eps produced: -a e_cfg + b e_uncond with a ~ b, so the
+                           # update is a difference of nearly equal terms and a 3.6e-3 error of eps shows as 1.6e-2 ... 2.2e-2 of it)
 TOL_START_STEP = 6e-2      # the start step: 1 + 2 * resampling_steps = 21 chained UNet calls at sqrt(alpha_t) ~ 0.07
 TOL_FINAL = {"bf16": 6e-2, "fp8": 1e-1}      # final latent of the free-running trajectory (45 chained calls; 75 at 1024^2 n = 50)
 TOL_EPS_FREE_FUSION = {"bf16": 8e-2, "fp8": 1.2e-1}   # eps of the fusion window's calls along the two FREE-RUNNING trajectories (carries the latent drift)
-FLOOR_VISIBLE = 1e-5       # a teacher-forced error below this inside the fusion window means the metric no longer sees eps (round 5's degenerate case)
+FLOOR_VISIBLE = 1e-5       # a teacher-forced error below this inside the fusion window (t > 1) means the metric no longer sees eps (round 5's degenerate case: 6e-15)
+FLOOR_UPDATE_FRACTION = 1e-3   # ... and so does an update that is less than this fraction of ||x'||
 MAX_ABS_LATENT = 60.0      # |x| along the oracle's trajectory with partition masks (x_T ~ N(0,1); the final latent is an x0 estimate)
 
 
@@ -54,7 +62,8 @@ def test_full_size_trajectory_vs_oracle_sampler(sdxl_weights, sdxl_bundles, kind
     assert r["teacher_forced_worst_other_step_update_normalised"] <= TOL_STEP_UPDATE, r
     fw = r["fusion_window"]
     assert fw["steps"] == (13 if kind == "lora" else 16)      # the LoRA window [t_cond, t_stop] keeps its off-by-one step at t_stop (fusion_base plan)
-    assert fw["teacher_forced_min"] >= FLOOR_VISIBLE, f"the fusion window is invisible to the step metric: {fw}"
+    assert fw["teacher_forced_min"] >= FLOOR_VISIBLE and fw["update_fraction_min"] >= FLOOR_UPDATE_FRACTION, f"the fusion window is invisible to the step metric: {fw}"
+    assert fw["update_normalised_max"] <= TOL_STEP_UPDATE and fw["eps_first_call_max"] <= TOL_EPS_CALL, fw
     assert r["free_running_eps_worst_fusion"] <= TOL_EPS_FREE_FUSION[r["dtype"]], r
     assert r["free_running_final_rel_l2"] <= TOL_FINAL[r["dtype"]], r
 

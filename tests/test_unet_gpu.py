@@ -339,7 +339,7 @@ def _oracle_concepts(kind, con):
     return UO.Concepts("lora", lora=lo)
 
 
-def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged", call_kind="fusion", n_seeds=1):
+def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged", call_kind="fusion", n_seeds=1, bundle=None):
     """a UNet plan EXACTLY as bench.py's timed regions build it: bench.build_sampler's Tweediemix (same flags, concept routing,
     `streams` launch chains, `n_seeds` co-batched trajectories, shipped tile table) -> tw.plan(call_kind), i.e.
     sampler.Tweediemix._build_plan.  call_kind "fusion" (the headline step: uncond + K concept rows, routed), "fusion_base" (the LoRA
@@ -347,8 +347,12 @@ def _timed_plan(sd, kind, hw, streams, fp8=False, lora_mode="merged", call_kind=
     "plain" (the B = 2 CFG pair).  Returns (plan, ehs, pooled, time_ids, concept state dicts); the prompt rows are ONE seed's (co-batched seeds repeat them)."""
     from tweediemix_amd import masks as M, sampler as S, unet as U, weights as Wt
     cfg, K = U.SDXL, 3
-    con = Wt.synthetic_concepts(cfg, kind, K, device="cuda")
-    W = U.UNetWeights(cfg, sd, "cuda", (kind, con), lora_mode=lora_mode)
+    if bundle is not None:                               # the session's (concepts, UNetWeights, oracle) for this kind (tests/conftest.py: built once)
+        con, W = bundle[0], bundle[1]
+        assert lora_mode == "merged" and W.kind == kind
+    else:
+        con = Wt.synthetic_concepts(cfg, kind, K, device="cuda")
+        W = U.UNetWeights(cfg, sd, "cuda", (kind, con), lora_mode=lora_mode)
     g = torch.Generator().manual_seed(5)
     te = (torch.randn(K + 2, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float(), torch.randn(K + 2, cfg.pooled_dim, generator=g))
     ts = (torch.randn(K, 77, cfg.cross_dim, generator=g).to(torch.bfloat16).float(), torch.randn(K, cfg.pooled_dim, generator=g))
@@ -387,7 +391,7 @@ def _graph_replay(plan, x, t):
 
 @pytest.mark.parametrize("streams", [1, 2])
 @pytest.mark.parametrize("kind,hw", [("custom", 128), ("lora", 128), ("lora", 64)])
-def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, streams):
+def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, sdxl_bundles, kind, hw, streams):
     """what bench.py TIMES, checked against the oracle: SDXL shapes at latent 128x128 (1024x1024: S = 16384 / 4096 / 1024 tokens,
     65,536-row convolutions), B = K+1 = 4 concept-routed rows, built by the sampler's own plan builder (see _timed_plan) --
     streams = 1: the DEFAULT one launch chain at the full batch (routed LoRA `row_sets`, un-prefixed tile-table entries);
@@ -396,7 +400,7 @@ def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, s
     what bench.py asserts for its timed plan too.  Tolerance as everywhere: rel L2 <= 2e-2, max-abs <= 5e-2 * max|ref|."""
     from oracle import unet_oracle as UO
     from tweediemix_amd import unet as U
-    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, kind, hw, streams)
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, kind, hw, streams, bundle=sdxl_bundles(kind))
     assert isinstance(plan, U.PlanGroup) == (streams == 2)
     assert all(p.routed == (kind == "lora") for p in U._plans_of(plan))
     if hw == 128:                                        # the size bench.py times: every launch shape is in the shipped table
@@ -405,7 +409,7 @@ def test_headline_size_timed_plan_graph_vs_fp32_oracle(sdxl_weights, kind, hw, s
     g = torch.Generator().manual_seed(6)
     x = torch.randn(1, 4, hw, hw, generator=g).repeat(4, 1, 1, 1).cuda()
     eps = _graph_replay(plan, x, 601)
-    ref = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    ref = sdxl_bundles(kind)[2].forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
     torch.cuda.synchronize()
     r = rel_l2(eps, ref)
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
@@ -422,7 +426,7 @@ _CALL_CASES = [(ck, ns) for ck in ("fusion", "fusion_base", "start", "plain") fo
 
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("call_kind,n_seeds", _CALL_CASES)
-def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, call_kind, n_seeds, fp8):
+def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, sdxl_bundles, call_kind, n_seeds, fp8):
     """SDXL shapes at latent 128x128 (what bench.py times), LoRA concepts, the sampler's own plan builder for `call_kind` and `n_seeds` co-batched
     trajectories (rows seed-major; every seed has its OWN latent), shipped tile table asserted, hipGraph replay -- against the fp32 oracle, one oracle
     call per seed (rows of different seeds never interact).  Reference call sites: fusion_sampling.py:324-340 (fusion rows), :342-359 (start rows),
@@ -431,7 +435,7 @@ def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, call_kind, n_seeds, 
     from oracle import unet_oracle as UO
     from tweediemix_amd import unet as U
     hw = 128
-    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, "lora", hw, 1, fp8=fp8, call_kind=call_kind, n_seeds=n_seeds)
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, "lora", hw, 1, fp8=fp8, call_kind=call_kind, n_seeds=n_seeds, bundle=sdxl_bundles("lora"))
     rows = ehs.shape[0]
     routed = call_kind == "fusion"
     assert plan.B == rows * n_seeds and plan.routed == routed and plan.fp8 == fp8
@@ -442,7 +446,7 @@ def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, call_kind, n_seeds, 
     xs = torch.randn(n_seeds, 1, 4, hw, hw, generator=g)
     x = xs.repeat(1, rows, 1, 1, 1).reshape(n_seeds * rows, 4, hw, hw).cuda()
     eps = _graph_replay(plan, x, 601)
-    orc = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts("lora", con))
+    orc = sdxl_bundles("lora")[2]
     worst = (0.0, 0.0)
     for s in range(n_seeds):
         sl = slice(s * rows, (s + 1) * rows)
@@ -455,7 +459,7 @@ def test_every_timed_call_kind_vs_fp32_oracle(sdxl_weights, call_kind, n_seeds, 
           f"max_rel={worst[1]:.4g} tilings={U.used_tilings(plan)}")
 
 
-def test_plain_plan_co_batched_rows_equal_the_single_seed_call_at_sdxl_size(sdxl_weights, monkeypatch):
+def test_plain_plan_co_batched_rows_equal_the_single_seed_call_at_sdxl_size(sdxl_weights, sdxl_bundles, monkeypatch):
     """whether attn2 runs as ONE launch (tmix_gemm_q_cross_attn: q rounded after scale * log2e, its own softmax) or as the to_q GEMM +
     attention pair must be a function of the image's shape only -- never of the batch -- or a co-batched seed stops matching its single-seed run.
     The B = 2 `plain` call at latent 128 x 128 (the 32 x 32 level's 64 tiles per image) against the same rows co-batched 2 x (B = 4), ONE tiling
@@ -463,8 +467,8 @@ def test_plain_plan_co_batched_rows_equal_the_single_seed_call_at_sdxl_size(sdxl
     the first seed's rows equal bit for bit.  Call sites: fusion_sampling.py:360-374,406,440."""
     monkeypatch.setenv("TMIX_FORCE_TILE", "1")
     hw = 128
-    one, ehs, pooled, tid, _con = _timed_plan(sdxl_weights, "lora", hw, 1, call_kind="plain", n_seeds=1)
-    two, _e, _p, _t, _c = _timed_plan(sdxl_weights, "lora", hw, 1, call_kind="plain", n_seeds=2)
+    one, ehs, pooled, tid, _con = _timed_plan(sdxl_weights, "lora", hw, 1, call_kind="plain", n_seeds=1, bundle=sdxl_bundles("lora"))
+    two, _e, _p, _t, _c = _timed_plan(sdxl_weights, "lora", hw, 1, call_kind="plain", n_seeds=2, bundle=sdxl_bundles("lora"))
     assert one.B == 2 and two.B == 4
 
     def names(plan):
@@ -514,17 +518,17 @@ def test_fp8_projections_tiny_unet_vs_oracle():
 
 
 @pytest.mark.parametrize("kind,hw", [("lora", 128), ("custom", 64)])
-def test_fp8_projections_full_size_sdxl_vs_oracle(sdxl_weights, kind, hw):
+def test_fp8_projections_full_size_sdxl_vs_oracle(sdxl_weights, sdxl_bundles, kind, hw):
     """the fp8 bench leg (`other_configs.fp8`: one chain at B = 4, latent 128 x 128, LoRA rows; and Custom-Diffusion rows at 64 x 64)
     built by the sampler's own builder, hipGraph replay, vs the fp32 oracle.  Bound: whole-UNet rel-L2 <= 2e-2 -- the SAME bound as
     the bf16 path (measured 5.4e-3 fp8 vs 5.3e-3 bf16: e4m3 operands with power-of-two block scales cost less than bf16 activations)."""
     from oracle import unet_oracle as UO
-    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, kind, hw, 1, fp8=True)
+    plan, ehs, pooled, tid, con = _timed_plan(sdxl_weights, kind, hw, 1, fp8=True, bundle=sdxl_bundles(kind))
     assert plan.fp8
     g = torch.Generator().manual_seed(6)
     x = torch.randn(1, 4, hw, hw, generator=g).repeat(4, 1, 1, 1).cuda()
     eps = _graph_replay(plan, x, 601)
-    ref = UO.UNetOracle(UO.SDXL, sdxl_weights, _oracle_concepts(kind, con)).forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
+    ref = sdxl_bundles(kind)[2].forward(x, 601, ehs.cuda(), pooled.cuda(), tid.cuda(), routed=True)
     r = rel_l2(eps, ref)
     m = (eps - ref).abs().max().item() / ref.abs().max().item()
     print(f"SDXL {kind} {hw * 8}^2 B=4 fp8 projections, one chain, graph replay: rel_l2={r:.4g} max_rel={m:.4g}")

@@ -182,10 +182,13 @@ def trajectory_parity(sd, kind="lora", res=512, n=20, fp8=False, K=3, resampling
         res_d["teacher_forced_start_step_update_normalised"] = per_upd[0][1]
         res_d["teacher_forced_worst_other_step_update_normalised"] = max(r for _t, r, _u in per_upd[1:])
         res_d["teacher_forced_worst_eps_first_call"] = max(r for _t, r in per_eps)
-        fw = [(r, ru, re) for (t, r), (_t2, ru, _u), (_t3, re) in zip(per, per_upd, per_eps) if t in set(int(v) for v in in_win)]
+        win = set(int(v) for v in in_win)
+        fw = [(t, r, ru, uf, re) for (t, r), (_t2, ru, uf), (_t3, re) in zip(per, per_upd, per_eps) if t in win]
         if fw:
-            res_d["fusion_window"] = {"steps": len(fw), "teacher_forced_min": min(r for r, _u, _e in fw), "teacher_forced_max": max(r for r, _u, _e in fw),
-                                      "update_normalised_max": max(u for _r, u, _e in fw), "eps_first_call_max": max(e for _r, _u, e in fw)}
+            # (the last scheduler step, t == 1, returns x0 with alpha_t ~ 1: eps weighs 3e-3 of it by construction -- kept out of the "visible" floor, not out of the maxima)
+            res_d["fusion_window"] = {"steps": len(fw), "teacher_forced_min": min(r for t, r, *_x in fw if t != 1), "teacher_forced_max": max(r for _t, r, *_x in fw),
+                                      "update_normalised_min": min(u for _t, _r, u, _f, _e in fw), "update_normalised_max": max(u for _t, _r, u, _f, _e in fw),
+                                      "update_fraction_min": min(f for _t, _r, _u, f, _e in fw), "eps_first_call_max": max(e for *_x, e in fw)}
     return res_d
 
 

@@ -19,6 +19,8 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     if (cfg <= 0 || cfg > NUM_CFG) cfg = pick_cfg(p, batch);
     if (cfg == 8) cfg = 19; else if (cfg == 9) cfg = 2; else if (cfg == 10) cfg = 1; else if (cfg == 11) cfg = 4;   // round-1 loader-wave tilings, retired (3 waves / SIMD register budget: they spilled)
     // 23 = 128x160 over 2 x 2 math waves of 64x80 (v_mfma_f32_16x16x32_bf16) + four loader waves (gemm_w22.hip): the staged plain bf16 epilogue only
+    // 26 = the halo-patch convolution (gemm_convh.hip): stride 1, bf16, 4 x 32 pixel tiles; anything it does not carry runs as the loader-wave tilings 20 (conv) / 21 (GEMM)
+    if (cfg == 26) { if (convh_eligible(p, conv, p.scaleA != nullptr)) return launch_convh(p, st); cfg = conv ? 20 : 21; }
 #ifdef TMIX_EXPERIMENTAL_TILINGS      // dev variants (make EXPERIMENTAL=1): 24 = 256x320 on persistent workgroups (gemm_ff1p.hip), 25 = tiling 23 with an L2 prefetcher wave
     if (cfg == 23 || cfg == 25) { if (w22_eligible(p, conv, 0)) return launch_w22(p, batch, st, cfg == 25); cfg = conv ? 12 : 21; }
     if (cfg == 24) { if (ff1p_eligible(p, conv, 0, batch)) return launch_ff1p(p, st); cfg = 14; }
@@ -36,7 +38,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
         }
     }
     if (p.f8copy) {                // the e4m3 copy of C is compiled into the tilings that have registers to spare for it (F8C)
-        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12, 12, 12, 12, 12};
+        static const int alt[NUM_CFG + 1] = {0, 1, 2, 3, 4, 5, 4, 7, 7, 2, 1, 4, 12, 13, 12, 15, 16, 17, 18, 12, 12, 12, 12, 12, 12, 12, 12};
         // (every substitute keeps the tile width, and with it the number of row-statistics partials, except 256x320 -> 128x160)
         if (cfg == 14 && p.stats_out) TMIX_FAIL(TMIX_EINVAL, "gemm: the e4m3 copy is not compiled into tiling 14; with row_stats_out pick another tiling (the partial count depends on it)");
         if (!((cfg == 19 || cfg == 20 || cfg == 21) && !conv && p.scaleA && p.K % 128 == 0)) cfg = alt[cfg];      // (the loader-wave tilings on e4m3 operands carry the copy themselves)
@@ -99,7 +101,7 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
 extern "C" int tmix_gemm_tile_shape(int tile_cfg, int* bm, int* bn) {
     static const int shape[NUM_CFG + 1][2] = {{0, 0}, {128, 128}, {256, 128}, {128, 128}, {256, 256}, {256, 128}, {256, 256}, {128, 160},
                                               {128, 160}, {256, 128}, {128, 128}, {256, 256}, {128, 160}, {64, 160}, {256, 320}, {32, 160},
-                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}, {128, 160}, {256, 320}, {128, 160}, {256, 320}, {128, 160}};
+                                              {256, 256}, {256, 128}, {128, 160}, {128, 160}, {128, 160}, {128, 160}, {256, 320}, {128, 160}, {256, 320}, {128, 160}, {128, 160}};
     if (tile_cfg < 1 || tile_cfg > NUM_CFG || !bm || !bn) TMIX_FAIL(TMIX_EINVAL, "gemm_tile_shape: tile_cfg=%d", tile_cfg);
     *bm = shape[tile_cfg][0]; *bn = shape[tile_cfg][1];
     return TMIX_OK;

@@ -1581,7 +1581,8 @@ struct TileCfg { int bm, bn; };
 // 23 = 128x160 over 2 x 2 math waves of 64x80 on v_mfma_f32_16x16x32_bf16 + four loader waves (its own kernel: gemm_w22.hip)
 // 24 = 256x320 (tiling 14's tile and arithmetic) on PERSISTENT workgroups: one per CU walks its tiles, the next tile's first K-tile requested under the last one (gemm_ff1p.hip)
 // 25 = tiling 23 with the fourth loader wave as an L2 PREFETCHER (touches the tile's operand lines eight K-tiles ahead of the ring)
-constexpr int NUM_CFG = 25;
+// 26 = 3x3 stride-1 convolution with the input halo patch resident in LDS (4 x 32 pixel tiles, channel-chunk-major K loop; its own kernel: gemm_convh.hip)
+constexpr int NUM_CFG = 26;
 
 template <int BM, int BN, int WM, int WN, int NS, int CONV, int LW = 0, int PH = 0, int KS = 1, int CS = 0, int EK = 0, int SC = 0>
 int launch_cfg(Params& p, int batch, hipStream_t st) {
@@ -1639,6 +1640,8 @@ bool w22_eligible(const Params& p, int conv, int f8);                           
 int launch_w22(Params& p, int batch, hipStream_t st, int l2_prefetcher = 0);            // (1: tiling 25, three DMA loaders + an L2 prefetcher wave)
 bool ff1p_eligible(const Params& p, int conv, int f8, int batch);                        // gemm_ff1p.hip (tiling 24)
 int launch_ff1p(Params& p, hipStream_t st);
+bool convh_eligible(const Params& p, int conv, int f8);                                 // gemm_convh.hip (tiling 26)
+int launch_convh(Params& p, hipStream_t st);
 // gemm_qattn.hip: attn2.to_q + the cross-attention behind it in one launch (tmix_gemm_q_cross_attn)
 struct QAExtra { const void* K; int64_t ldk, strideK; const void* Vt; int64_t ldvt, strideVt; void* O; int64_t ldo; int rows_per_image, Skv; float scale; };
 int launch_qattn(Params& p, const QAExtra& x, int batch, hipStream_t st);

@@ -17,13 +17,14 @@ STEP_FUSION, STEP_PLAIN, STEP_RESAMPLE = 0, 1, 2
 EPI_NONE, EPI_GEGLU, EPI_F32OUT, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3, 4
 CONV_S1, CONV_S2, CONV_UP2, CONV_T3, CONV_S2A = 0, 1, 2, 3, 4
 F8_A_BLOCK_SCALES, F8_GEGLU_OUT, F8_COPY_OUT = 1, 2, 4    # tmix_gemm_desc.reserved0 flags (the first two: tmix_gemm_fp8 only)
-TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 25, 7       # 6, 8..11: retired ids (run as 4, 19, 2, 1, 4)
+TILE_AUTO, TILE_COUNT, TILE_COUNT_CONV = 0, 26, 7       # 6, 8..11: retired ids (run as 4, 19, 2, 1, 4)
 TILE_CANDIDATES = (1, 2, 3, 4, 5, 7, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22)          # what the autotuner times by default (16, 17: phase-offset mainloop).  NOT 23: its 16x16x32 MFMAs add up a row's products in another order than the 32x32x16 tilings (which are bit-identical among themselves), so a tuner that picked it for one plan and not for its co-batched twin broke test_two_seeds_co_batched_equal_independent_runs; in situ it is level with 21 anyway.  Nor 24 (256x320 on persistent workgroups, same bits as 14): 5 % ahead hot, 5 % behind in situ
 TILE_EXCLUSIVE = (13, 14, 15, 22, 24)                                  # one workgroup per CU over the whole chip: not beside a sibling chain
 # gemm_conv.hip:launch substitutes these tilings when a bf16 GEMM also leaves the e4m3 copy of its output (TMIX_F8_COPY_OUT is
 # compiled into the tilings with registers to spare).  The plan builder applies the same map to the DESCRIPTOR, so the number of
 # row-statistics partials the consumers are told (tmix_gemm_stats_parts) is that of the kernel that really runs.
-F8COPY_TILE_ALT = {6: 4, 8: 7, 9: 2, 10: 1, 11: 4, 14: 12, 19: 12, 20: 12, 21: 12, 22: 12, 23: 12, 24: 12, 25: 12}
+F8COPY_TILE_ALT = {6: 4, 8: 7, 9: 2, 10: 1, 11: 4, 14: 12, 19: 12, 20: 12, 21: 12, 22: 12, 23: 12, 24: 12, 25: 12, 26: 12}
+TILE_CONV_HALO = 26                                              # gemm_convh.hip: stride-1 convolutions with the halo patch in LDS (conv launches only)
 TILE_LW = (19, 20, 21)                                           # loader-wave tilings: GEMM only, except 20 (a conv launch runs 19 / 21 as tiling 12)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
