@@ -20,7 +20,7 @@ for (B, H, W, Ci, Co) in ((4, 128, 128, 320, 320), (4, 128, 128, 640, 320), (4, 
     out = torch.empty(B, H, W, Co, device="cuda", dtype=BF); bias = torch.randn(Co, device="cuda"); temb = torch.randn(B, Co, device="cuda")
     cs = ops.colstats_buf(B * H * W, Co, "cuda")
     row = []
-    for cfg in (12, 20, 26):
+    for cfg in (14, 20, 26):
         us = t(ops.make_conv_desc(x, w, out, bias, batch_bias=temb, mode=0, tile_cfg=cfg, col_stats_out=cs))
         row.append(f"c{cfg}:{us:7.1f}us/{2 * B * H * W * Co * 9 * Ci / us / 1e6:4.0f}TF ({us * 256 / (B * H * W // 128 * (Co // 160)) / (9 * Ci // 64) * 1e3:5.0f} ns/K-tile/round)")
     print(f"conv B={B} {H}x{W} {Ci}->{Co}: " + " ".join(row), flush=True)

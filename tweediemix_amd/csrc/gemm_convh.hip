@@ -243,7 +243,7 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
     // 8 g + 4 lhi + r of fragment j (register 4 g + r).  Per chunk the wave parks 32 pixels x 64 (32) fp32 columns in its LDS patch and reads them back
     // row-major: 8 (4) lanes x 8 columns per pixel, 16-byte residual loads (prefetched) and C stores.
     char* stg = smem + H_OFF_W + w * H_STG;
-    const int64_t blk = (int64_t)tile_m * 4 + w;       // this wave's 32-pixel block in cs_out: any bijection onto the image's blocks serves (gn_finalize_cs adds them all)
+    const int64_t blk = mrow0 >> 5;                    // the 32 pixels of this wave are one 32-row block of the NHWC matrix (x0 and Wo are multiples of 32): cs_out[M / 32][2][N] as every tiling writes it
     auto chunk = [&](int j0, auto cf_tag) __attribute__((always_inline)) {
         constexpr int CF = decltype(cf_tag)::value, CW = CF * 32, SR = CW * 4 + 16, LPR = CW / 8, RPI = 64 / LPR, NP = 32 / RPI;
         const int rr = lane / LPR, cc = (lane % LPR) * 8;

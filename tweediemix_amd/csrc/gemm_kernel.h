@@ -10,8 +10,8 @@
 //     and undone on the ds_read_b128 side; it is conflict-free for the 16-lane service groups of
 //     ds_read_b128 with 32-row MFMA fragments;
 //   * v_mfma_f32_32x32x16_bf16, wave tile (BM/WM) x (BN/WN), fp32 accumulation;
-//   * the convolution differs only in how a lane finds its source address (im2col on the fly: K-tile kt
-//     is tap kt / (Cin/64), channels (kt % (Cin/64))*64..+63 of the shifted pixel; padding taps read a
+//   * the convolution differs only in how a lane finds its source address (im2col on the fly: the K-tiles walk
+//     channel-chunk major -- 64 channels of the shifted pixel, the nine taps of a chunk back to back; padding taps read
 //     zeros via the buffer bounds check); stride-2 and nearest-x2 upsampling are folded into the gather;
 //   * fused epilogues: bias, per-row-group bias (time embedding), residual add, GEGLU, transposed store
 //     (V^T for the attention kernel), per-batch weight sets (concept routing).
@@ -258,7 +258,38 @@ gemm_conv_kernel(const Params p) {
     auto slot_w = [&](int r) { int i = r * SW + sw_id; if constexpr (IB % SW != 0) i = min(i, IB - 1); return i; };
     constexpr int RAa = (LW && !CONV) ? 1 : RA, RBa = LW ? 1 : RB;
     unsigned woff[RBa], aoff[RAa];
-    int pb[CONV ? RA : 1], py[CONV ? RA : 1], px[CONV ? RA : 1], asw[(CONV && !LW) ? RA : 1];
+    int asw[(CONV && !LW) ? RA : 1];
+    // convolution, per staged row: cbase = byte offset of the row's tap-(0, 0) source pixel (+ the row's swizzle; may be "negative": the tap delta brings it back),
+    // cmask = bit t: tap t reads inside the image (else zeros through the bounds check); bits 16 / 17: parity of the row's upsampled tap-(0, 0) coordinates (UP2);
+    // cpix (shortcut taps only) = the output pixel's index.  The K loop walks the taps of a channel chunk back to back, so a tap's offsets are derived every K-tile:
+    // one add and one select per row on top of a scalar tap delta (recomputing them from (image, y, x) cost the 256 x 320 tiling 50 % of its time)
+    unsigned cbase[CONV ? RA : 1], cmask[CONV ? RA : 1];
+    int cpix[(CONV && SC) ? RA : 1];
+    auto conv_row = [&](int r, int m, unsigned swb) __attribute__((always_inline)) {
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            const int py = rem / p.Wo, px = rem - py * p.Wo;
+            int iy0, ix0; unsigned par = 0;
+            if (p.mode == TMIX_CONV_S1 || p.mode == TMIX_CONV_T3) { iy0 = py - 1; ix0 = px - 1; }
+            else if (p.mode == TMIX_CONV_S2) { iy0 = 2 * py - 1; ix0 = 2 * px - 1; }
+            else if (p.mode == TMIX_CONV_S2A) { iy0 = 2 * py; ix0 = 2 * px; }
+            else { iy0 = (py - 1) >> 1; ix0 = (px - 1) >> 1; par = (unsigned)((py - 1) & 1) << 16 | (unsigned)((px - 1) & 1) << 17; }     // nearest x2: source = upsampled coordinate >> 1
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t >= p.ntaps) break;
+                const int ky = p.mode == TMIX_CONV_T3 ? t : t / 3, kx = p.mode == TMIX_CONV_T3 ? 1 : t - (t / 3) * 3;
+                bool ok;
+                if (p.mode == TMIX_CONV_UP2) { const int uy = py + ky - 1, ux = px + kx - 1; ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); }
+                else { const int iy = iy0 + ky, ix = ix0 + kx; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
+                mk |= (unsigned)ok << t;
+            }
+            cbase[r] = (unsigned)(((b * p.H + iy0) * p.Wd + ix0) * p.Cin) * (unsigned)EB + swb;
+            cmask[r] = mk | par;
+            if constexpr (SC) cpix[r] = (b * p.H + py) * p.Wd + px;
+        }
+    };
     unsigned aoffp[2], amaxp[2], woffp[2], wmaxp[2], swp[2];
     if constexpr (LW) {
         if (loader) {
@@ -273,12 +304,10 @@ gemm_conv_kernel(const Params p) {
                 amaxp[pp] = (unsigned)(p.M - 1) * (unsigned)p.lda * (unsigned)EB + sw * 2u;
             }
             if constexpr (CONV) {
-                const int hw = p.Ho * p.Wo;
 #pragma unroll
                 for (int r = 0; r < RA; ++r) {
                     int m = m0l + slot_a(r) * 8 + lrow; if (m > p.M - 1) m = p.M - 1;      // (the rows of THIS loader's r-th instruction)
-                    pb[r] = m / hw; const int rem = m - pb[r] * hw;
-                    py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
+                    conv_row(r, m, swp[r & 1] * 2u);
                 }
             }
         }
@@ -298,9 +327,7 @@ gemm_conv_kernel(const Params p) {
         int m = m0l + idx * 8 + lrow; if (m > p.M - 1) m = p.M - 1;
         asw[r] = sw;
         if constexpr (CONV) {
-            const int hw = p.Ho * p.Wo;
-            pb[r] = m / hw; const int rem = m - pb[r] * hw;
-            py[r] = rem / p.Wo; px[r] = rem - py[r] * p.Wo;
+            conv_row(r, m, (unsigned)sw * 2u);
             aoff[r] = 0;
         } else {
             aoff[r] = (unsigned)m * (unsigned)p.lda * (unsigned)EB + (unsigned)sw * 2u;
@@ -360,23 +387,26 @@ gemm_conv_kernel(const Params p) {
                 const int Cs = tap == p.ntaps ? p.c1s : p.c2s;
 #pragma unroll
                 for (int r = 0; r < RA; ++r)
-                    cvo[r] = (unsigned)(((pb[r] * p.H + py[r]) * p.Wd + px[r]) * Cs + (LW ? (int)swp[r & 1] : asw[LW ? 0 : r])) * 2u;
+                    cvo[r] = (unsigned)(cpix[r] * Cs + (LW ? (int)swp[r & 1] : asw[LW ? 0 : r])) * 2u;
                 cpt = Cs / BK;
                 return;
             }
         }
         // TMIX_CONV_T3: a (3,1,1) kernel over the first (frame) axis only -- 3 taps, kx fixed at the centre
         const int ky = p.mode == TMIX_CONV_T3 ? tap : tap / 3, kx = p.mode == TMIX_CONV_T3 ? 1 : tap - ky * 3;
+        const unsigned pixb = (unsigned)p.Cin * (unsigned)EB, rowb = (unsigned)p.Wd * pixb;         // bytes of a source pixel / of a source row
+        if (p.mode == TMIX_CONV_UP2) {
+            // nearest x2: source row = (uy0 + ky) >> 1 = (uy0 >> 1) + {0, parity of uy0, 1}[ky], columns alike
+            const unsigned sd = (ky == 2 ? rowb : 0u) + (kx == 2 ? pixb : 0u), ay = ky == 1 ? rowb : 0u, ax = kx == 1 ? pixb : 0u;
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            int iy, ix; bool ok;
-            if (p.mode == TMIX_CONV_S1 || p.mode == TMIX_CONV_T3) { iy = py[r] + ky - 1;     ix = px[r] + kx - 1;     ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
-            else if (p.mode == TMIX_CONV_S2) { iy = 2 * py[r] + ky - 1; ix = 2 * px[r] + kx - 1; ok = (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd); }
-            else if (p.mode == TMIX_CONV_S2A) { iy = 2 * py[r] + ky; ix = 2 * px[r] + kx; ok = (iy < p.H) & (ix < p.Wd); }   // pad right / bottom only
-            else { const int uy = py[r] + ky - 1, ux = px[r] + kx - 1;   // conv over the nearest-x2 upsampled image
-                   ok = (uy >= 0) & (uy < 2 * p.H) & (ux >= 0) & (ux < 2 * p.Wd); iy = uy >> 1; ix = ux >> 1; }
-            const unsigned sw = LW ? swp[r & 1] : (unsigned)asw[LW ? 0 : r];
-            cvo[r] = ok ? (unsigned)((pb[r] * p.H + iy) * p.Wd + ix) * (unsigned)p.Cin * (unsigned)EB + sw * 2u : 0x80000000u;
+            for (int r = 0; r < RA; ++r) {
+                const unsigned o = cbase[r] + sd + ((cmask[r] >> 16) & 1u) * ay + ((cmask[r] >> 17) & 1u) * ax;
+                cvo[r] = ((cmask[r] >> tap) & 1u) ? o : 0x80000000u;
+            }
+        } else {
+            const unsigned sd = (unsigned)ky * rowb + (unsigned)kx * pixb;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) cvo[r] = ((cmask[r] >> tap) & 1u) ? cbase[r] + sd : 0x80000000u;
         }
         if constexpr (CONV && SCP) {                   // the same tap for this wave's scale rows: byte offset of the row's Cin / 32 scales
             int iy, ix; bool ok;
@@ -421,6 +451,14 @@ gemm_conv_kernel(const Params p) {
         char* sA = smem + buf * STAGE;
         char* sW = sA + A_TILE;
         bool a_done = false;
+        // byte offset of this K-tile inside a weight row: the plain GEMM walks K in order; the convolution's cursor (tap, cc) walks CHANNEL-CHUNK major
+        // (see the cursor advance below), weight rows are [tap][Cin] (+ the shortcut tensors' channels behind the taps)
+        unsigned wk = (unsigned)kt * (BK * 2);
+        if constexpr (CONV) {
+            const int tap_u = __builtin_amdgcn_readfirstlane(tap), cc_u = __builtin_amdgcn_readfirstlane(cc);
+            if (SC && tap_u >= p.ntaps) wk = (unsigned)(p.ntaps * p.Cin + (tap_u > p.ntaps ? p.c1s : 0)) * 2u + (unsigned)cc_u * (BK * 2);
+            else wk = (unsigned)(tap_u * p.Cin) * (unsigned)EB + (unsigned)cc_u * (BK * 2);
+        }
         if constexpr (CONV && SC) {
             // the A source of this K-tile: the conv input for the nine taps, then the shortcut tensors.  The cursor is wave-uniform (said explicitly),
             // and the choice is made on plain pointers -- a select between buffer RESOURCES goes through scratch memory and waterfall loops
@@ -443,11 +481,21 @@ gemm_conv_kernel(const Params p) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             if constexpr (LW) blds16(rsW, min(woffp[(r * LW) & 1] + (unsigned)(slot_w(r) >> 1) * (unsigned)(16 * EB * p.ldw), wmaxp[(r * LW) & 1]),
-                                     (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
-            else              blds16(rsW, woff[r], (unsigned)kt * (BK * 2), sW + slot_w(r) * 1024);
+                                     wk, sW + slot_w(r) * 1024);
+            else              blds16(rsW, woff[r], wk, sW + slot_w(r) * 1024);
         }
         scale_piece(sA, kt);
-        if constexpr (CONV) { if (++cc == cpt) { cc = 0; ++tap; if (tap < ntaps_all) conv_tap_offsets(); } }
+        if constexpr (CONV) {
+            // K order of the convolution (round 6): CHANNEL-CHUNK major, the taps of a 64-channel chunk back to back.  Tap-major (rounds 1-5) re-read an input pixel
+            // Cin / 64 K-tiles after its neighbour tap had fetched it -- by then the XCD's 4 MB L2 had turned over (32 resident tiles x 36-72 KB per K-tile) and the
+            // re-read went through the fabric: FETCH_SIZE 4.5 x algorithmic.  Now the kx neighbours are consecutive K-tiles and the ky neighbours three apart.  The
+            // per-lane tap offsets are recomputed every K-tile (a dozen VALU instructions per staged row, under the MFMAs); the shortcut tensors keep their order.
+            if (SC && tap >= p.ntaps) { if (++cc == cpt) { cc = 0; ++tap; if (tap < ntaps_all) conv_tap_offsets(); } }
+            else {
+                if (++tap == p.ntaps) { tap = 0; if (++cc == cpt) { cc = 0; tap = p.ntaps; } }
+                if (tap < ntaps_all) conv_tap_offsets();
+            }
+        }
     };
 
     // ---- loader wave (LW): leaves here, before any math-wave state (accumulators, fragments) becomes live

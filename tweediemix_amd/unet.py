@@ -1199,6 +1199,10 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
         for cfg in (cands or L.TILE_CANDIDATES):
             if cfg == cur or (cfg in L.TILE_EXCLUSIVE and len(plans) > 1) or (members[k][0][1] == "conv" and cfg in (16, 17, 18, 19, 21, 22, 23, 24, 25)):
                 continue
+            if cfg == L.TILE_CONV_HALO:               # the halo-patch kernel: convolutions it can run only (anything else would be timed under an alias of 20 / 21)
+                d0 = members[k][0][2]
+                if members[k][0][1] != "conv" or d0.mode != L.CONV_S1 or d0.S1_channels or d0.W % 32 or d0.H % 4 or d0.Cout % 160:
+                    continue
             for p, _kind, d in members[k]:
                 d.tile_cfg = cfg
             for p in plans:
