@@ -10,6 +10,7 @@ ap.add_argument("--cobatch", type=int, default=0); ap.add_argument("--top", type
 ap.add_argument("--cands", default="")       # e.g. 2,12,20,21: only these tilings are tried (default: every candidate)
 ap.add_argument("--kinds", default="lora,custom")
 ap.add_argument("--only-cobatch", action="store_true")       # skip the single-seed plans (refine the N-seed entries only)
+ap.add_argument("--only-kind", default="")                   # "conv" / "gemm": re-rank that class only
 a = ap.parse_args()
 os.environ["TMIX_TUNE_FILE"] = a.src
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +24,7 @@ for seeds in (([] if a.only_cobatch else [1]) + ([a.cobatch] if a.cobatch else [
         tw, _ = bench.build_sampler(args, kind, dev, seed=7)
         for name, top in (("fusion", a.top), ("plain", a.top // 2)):
             ms = tw.plan(name).refine(top=top if seeds == 1 else top // 2, reps=a.reps if seeds == 1 else 5, verbose=True,
-                                       cands=[int(c) for c in a.cands.split(',')] if a.cands else None)
+                                       cands=[int(c) for c in a.cands.split(',')] if a.cands else None, only_kind=a.only_kind or None)
             print(f"refined {kind} seeds={seeds} {name}: {ms:.3f} ms per UNet call", flush=True)
         del tw
         torch.cuda.empty_cache()

@@ -113,7 +113,11 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
         // weight K-tile (chunk c, tap t): channels [64 c, 64 c + 64) of tap t of every output row -- OHWI rows of 9 * Cin elements
         auto stage_w = [&](int slot, int c, int t) __attribute__((always_inline)) {
             char* dst = smem + H_OFF_W + slot * H_WT;
+#ifdef TMIX_ABL_WSEQ      // dev A/B builds only (wrong results, timing valid): the weight K-tiles read as if the rows were stored chunk-major, i.e. consecutive 128-byte pieces
+            const unsigned so = (unsigned)(c * 9 + t) * (BK * 2u);
+#else
             const unsigned so = (unsigned)(t * p.Cin + c * BK) * 2u;
+#endif
 #pragma unroll
             for (int r = 0; r < H_LWI; ++r) blds16(rsW, woff[r], so, dst + (r * H_LW + s) * 1024);
         };

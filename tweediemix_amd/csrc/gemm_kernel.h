@@ -454,11 +454,13 @@ gemm_conv_kernel(const Params p) {
         // byte offset of this K-tile inside a weight row: the plain GEMM walks K in order; the convolution's cursor (tap, cc) walks CHANNEL-CHUNK major
         // (see the cursor advance below), weight rows are [tap][Cin] (+ the shortcut tensors' channels behind the taps)
         unsigned wk = (unsigned)kt * (BK * 2);
-        if constexpr (CONV) {
+#ifndef TMIX_ABL_WSEQ     // (dev A/B builds: keep the sequential walk of the weight rows under the chunk-major A gather -- wrong results, timing valid)
+        if constexpr (CONV && !LW) {
             const int tap_u = __builtin_amdgcn_readfirstlane(tap), cc_u = __builtin_amdgcn_readfirstlane(cc);
             if (SC && tap_u >= p.ntaps) wk = (unsigned)(p.ntaps * p.Cin + (tap_u > p.ntaps ? p.c1s : 0)) * 2u + (unsigned)cc_u * (BK * 2);
             else wk = (unsigned)(tap_u * p.Cin) * (unsigned)EB + (unsigned)cc_u * (BK * 2);
         }
+#endif
         if constexpr (CONV && SC) {
             // the A source of this K-tile: the conv input for the nine taps, then the shortcut tensors.  The cursor is wave-uniform (said explicitly),
             // and the choice is made on plain pointers -- a select between buffer RESOURCES goes through scratch memory and waterfall loops
@@ -490,7 +492,9 @@ gemm_conv_kernel(const Params p) {
             // Cin / 64 K-tiles after its neighbour tap had fetched it -- by then the XCD's 4 MB L2 had turned over (32 resident tiles x 36-72 KB per K-tile) and the
             // re-read went through the fabric: FETCH_SIZE 4.5 x algorithmic.  Now the kx neighbours are consecutive K-tiles and the ky neighbours three apart.  The
             // per-lane tap offsets are recomputed every K-tile (a dozen VALU instructions per staged row, under the MFMAs); the shortcut tensors keep their order.
-            if (SC && tap >= p.ntaps) { if (++cc == cpt) { cc = 0; ++tap; if (tap < ntaps_all) conv_tap_offsets(); } }
+            // (The loader-wave instantiations -- tiling 20 -- keep the tap-major walk: their two loaders are the launch's critical path, and with the offsets
+            // derived every K-tile and the weight rows walked tap-strided they lost 42 % hot, 152 vs 107 us at 32 x 32 1280 -> 1280; tools/jobs6_wseq.sh.)
+            if (LW || (SC && tap >= p.ntaps)) { if (++cc == cpt) { cc = 0; ++tap; if (tap < ntaps_all) conv_tap_offsets(); } }
             else {
                 if (++tap == p.ntaps) { tap = 0; if (++cc == cpt) { cc = 0; tap = p.ntaps; } }
                 if (tap < ntaps_all) conv_tap_offsets();

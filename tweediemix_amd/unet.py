@@ -1153,7 +1153,7 @@ class UNetPlan:
 LN_COND_WARN = 16.0       # |mean| / std of a LayerNorm row beyond which a bf16 hidden state is itself the problem (its rounding noise > 2 % of the row's std)
 
 
-def refine_group(self, top=14, reps=9, verbose=False, cands=None):
+def refine_group(self, top=14, reps=9, verbose=False, cands=None, only_kind=None):
     """second tuning pass, for the chains of a group or for ONE plan (the event-timed eager ranking of UNetPlan.autotune is noisy
     at the +-1 % level, and a captured graph schedules launches differently from eager issue): UNetPlan.autotune ranks tilings with one chain running alone, but a
     tiling that owns its CU (one workgroup, deep ring) can lose once the other chain competes for the same CUs.  For the
@@ -1193,6 +1193,8 @@ def refine_group(self, top=14, reps=9, verbose=False, cands=None):
             weight[k] = weight.get(k, 0.0) + fl
             members.setdefault(k, []).append((p, kind, d))
     base = timed()
+    if only_kind is not None:                          # e.g. "conv": re-rank the convolutions only (a kernel change that touches one class)
+        weight = {k: v for k, v in weight.items() if members[k][0][1] == only_kind}
     for k in sorted(weight, key=weight.get, reverse=True)[:top]:
         cur = members[k][0][2].tile_cfg
         best, best_t = cur, base
