@@ -656,7 +656,7 @@ def test_conv3x3_with_the_halo_patch_in_lds(ops, B, H, W, Cin, Cout, extra):
 
 
 def test_halo_conv_falls_back_for_launches_it_does_not_carry(ops):
-    """stride 2, nearest x2, shortcut taps, a width that is not a multiple of 32 or of 160 output channels run as tiling 20: the same bits as asking for it"""
+    """stride 2, nearest x2, a width that is not a multiple of 32 or of 160 output channels (with or without shortcut taps) run as tiling 20: the same bits as asking for it"""
     from tweediemix_amd import lib as L
     x = rnd(2, 16, 16, 64, seed=510)
     w = rnd(160, 3, 3, 64, seed=511, scale=(9 * 64) ** -0.5)
@@ -666,9 +666,32 @@ def test_halo_conv_falls_back_for_launches_it_does_not_carry(ops):
     w2 = rnd(128, 3, 3, 64, seed=513, scale=(9 * 64) ** -0.5)      # Cout = 128
     assert torch.equal(ops.conv3x3(x2, w2, tile_cfg=L.TILE_CONV_HALO), ops.conv3x3(x2, w2, tile_cfg=20))
     wsc = rnd(160, 64, seed=514, scale=64 ** -0.5)
-    x1 = rnd(1, 8, 32, 64, seed=515)
-    assert torch.equal(ops.conv3x3(x2, ops.shortcut_weight(w, wsc), tile_cfg=L.TILE_CONV_HALO, shortcut=(x1, None)),
-                       ops.conv3x3(x2, ops.shortcut_weight(w, wsc), tile_cfg=20, shortcut=(x1, None)))
+    x1 = rnd(2, 16, 16, 64, seed=515)                              # shortcut taps on a 16-wide image: not its geometry either
+    assert torch.equal(ops.conv3x3(x, ops.shortcut_weight(w, wsc), tile_cfg=L.TILE_CONV_HALO, shortcut=(x1, None)),
+                       ops.conv3x3(x, ops.shortcut_weight(w, wsc), tile_cfg=20, shortcut=(x1, None)))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,c1,c2,cs", [(1, 4, 32, 64, 160, 64, 0, False), (1, 32, 32, 128, 320, 192, 128, True), (2, 8, 64, 64, 160, 64, 64, False),
+                                                     (1, 32, 32, 640, 1280, 1280, 640, True), (4, 64, 64, 640, 640, 320, 0, True), (2, 16, 32, 320, 320, 128, 192, False)])
+def test_halo_conv_with_shortcut_taps(ops, B, H, W, Cin, Cout, c1, c2, cs):
+    """ResnetBlock2D's conv2(h) + conv_shortcut(cat[x1, x2]) in ONE launch of the halo-patch kernel: behind the nine-tap chunks the K loop walks the shortcut tensors'
+    64-channel chunks as dense A tiles through the three-slot ring laid over the patch buffers (1 .. 30 shortcut K-tiles, last patch in either buffer)."""
+    from tweediemix_amd import lib as L
+    h = rnd(B, H, W, Cin, seed=520)
+    w = rnd(Cout, 3, 3, Cin, seed=521, scale=(9 * Cin) ** -0.5)
+    x1 = rnd(B, H, W, c1, seed=522)
+    x2 = rnd(B, H, W, c2, seed=523) if c2 else None
+    wsc = rnd(Cout, c1 + c2, seed=524, scale=(c1 + c2) ** -0.5)
+    bias = rnd(Cout, seed=525, dtype=torch.float32)
+    temb = rnd(B, Cout, seed=526, dtype=torch.float32)
+    csb = ops.colstats_buf(B * H * W, Cout, "cuda") if cs else None
+    out = ops.conv3x3(h, ops.shortcut_weight(w, wsc), bias=bias, batch_bias=temb, tile_cfg=L.TILE_CONV_HALO, shortcut=(x1, x2), col_stats_out=csb)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], -1)
+    ref = F.conv2d(h.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    ref = ref + xin @ wsc.float().T + temb[:, None, None, :]
+    close(out, ref)
+    if cs:
+        _colstats_close(csb, out)
 
 
 def test_column_statistics_reject_what_they_cannot_serve(ops):

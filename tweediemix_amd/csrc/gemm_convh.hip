@@ -15,8 +15,10 @@
 //     this chunk's taps multiply);
 //   * epilogue: the staged plain form -- bias, the image's time-embedding row, residual, bf16 store, GroupNorm column statistics (cs_out) -- rows mapped back
 //     from the tile's 4 x 32 block to NHWC pixel order.
-// Requirements (gemm_conv.hip routes everything else to the other tilings): mode TMIX_CONV_S1, bf16, Wo % 32 == 0, Ho % 4 == 0, Cout % 160 == 0, Cin % 64 == 0, no
-// shortcut taps, staged epilogue.  The accumulation order is chunk-major (the other tilings: tap-major): same products, another fp32 summation order.
+//   * shortcut taps (conv2 + conv_shortcut in one launch): behind the chunks the K loop walks 64-channel chunks of the block's input tensor(s) at the output
+//     pixel as dense A tiles through a three-slot ring laid over the patch buffers.
+// Requirements (gemm_conv.hip routes everything else to the other tilings): mode TMIX_CONV_S1, bf16, Wo % 32 == 0, Ho % 4 == 0, Cout % 160 == 0, Cin % 64 == 0,
+// staged epilogue.  The accumulation order is chunk-major (the other tilings: tap-major): same products, another fp32 summation order.
 //
 // MFMA roofline: 2 * B * H * W * Cout * 9 * Cin flops per launch against the 2.5 PFLOP/s dense bf16 peak.
 #include "gemm_kernel.h"
@@ -29,15 +31,19 @@ constexpr int H_BN = 160, H_NS = 4, H_LW = 4, H_NW = 4;
 constexpr int H_TR = 4, H_TC = 32;                       // output pixels of a tile: 4 rows x 32 columns = 128
 constexpr int H_PC = H_TC + 2, H_PRV = (H_TR + 2) * H_PC; // patch pitch (34 pixels) and valid patch rows (204)
 constexpr int H_PI = 28;                                  // LDS-DMA instructions per patch (8 rows of 128 bytes each): 224 rows, 7 per loader
-constexpr int H_PATCH = H_PI * 1024;                      // bytes of a patch buffer
+constexpr int H_PATCH = 32 * 1024;                        // distance of the two patch buffers (28 KB used each: [0, 28K) and [32K, 60K))
 constexpr int H_WT = H_BN * 128;                          // bytes of a weight stage (160 rows of 64 channels)
 constexpr int H_WI = H_BN / 8;                            // LDS-DMA instructions per weight stage: 20, 5 per loader
 constexpr int H_OFF_W = 2 * H_PATCH;                      // the weight ring sits behind the two patch buffers
+// shortcut taps (conv2 + conv_shortcut of a ResnetBlock2D in one launch): behind the nine-tap chunks the K loop walks 64-channel chunks of the block's INPUT at
+// the output pixel -- dense 128-row A tiles (16 KB, 4 LDS-DMA instructions per loader) through a ring of THREE slots laid over the patch region: with the last
+// patch in buffer b the slots are (b ? 0 : 32K) + {0, 16K, 32K} mod 64K, i.e. the first two lie in the free buffer and land while the last chunk's taps multiply
+constexpr int H_SA = 16 * 1024, H_LSA = 16 / H_LW;
 constexpr int H_MAIN = H_OFF_W + H_NS * H_WT;
 constexpr int H_LP = H_PI / H_LW, H_LWI = H_WI / H_LW;    // per loader: 7 patch, 5 weight instructions
 constexpr int H_STG = 32 * (64 * 4 + 16);                 // epilogue staging patch per wave (32 rows x 64 fp32 columns, rows padded by 16 bytes)
-static_assert(H_PI % H_LW == 0 && H_WI % H_LW == 0 && H_PI * 8 >= H_PRV, "loader geometry");
-static_assert(2 * H_LWI + H_LP <= 63, "vmcnt immediate");
+static_assert(H_PI % H_LW == 0 && H_WI % H_LW == 0 && H_PI * 8 >= H_PRV && H_PI * 1024 <= H_PATCH - 4096, "loader geometry");
+static_assert(2 * H_LWI + 2 * H_LSA <= 63 && 2 * H_LWI + H_LP <= 63, "vmcnt immediate");
 static_assert(H_NW * H_STG <= H_NS * H_WT, "epilogue patches fit in the weight ring");
 
 __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const Params p) {
@@ -82,6 +88,8 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
     const int ty = trem / txn, tx = trem - ty * txn;
     const int y0 = ty * H_TR, x0 = tx * H_TC;
     const int nchunks = p.Cin / BK;
+    const int n1 = p.S1 ? p.c1s / BK : 0, nsc = n1 + (p.S2 ? p.c2s / BK : 0);          // shortcut K-tiles (first tensor, both)
+    const int sa_base = ((nchunks - 1) & 1) ? 0 : H_PATCH;                             // slot j of the shortcut A ring: (sa_base + (j % 3) * 16K) mod 64K
 
     if (loader) {
         // ---- loader waves: LDS-DMA issue + counted waits only.  Loader s issues instructions g = 4 r + s of a patch (r < 7) and of a weight stage (r < 5); an
@@ -105,23 +113,40 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
             const unsigned sw = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
             woff[r] = (unsigned)(n0 + row) * (unsigned)p.ldw * 2u + sw;
         }
+        // shortcut A tile: instruction g = 4 r + s covers dense rows 8 g .. 8 g + 7 = pixels (y0 + row / 32, x0 + row % 32) of the tile
+        int spix[H_LSA]; unsigned ssw[H_LSA];
+#pragma unroll
+        for (int r = 0; r < H_LSA; ++r) {
+            const int row = (r * H_LW + s) * 8 + lrow;
+            spix[r] = (img * p.H + y0 + (row >> 5)) * p.Wd + x0 + (row & 31);
+            ssw[r] = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        }
+        auto stage_sa = [&](int j) __attribute__((always_inline)) {       // shortcut K-tile j (wave-uniform): chunk j of S1, or chunk j - n1 of S2
+            char* dst = smem + ((sa_base + (j % 3) * H_SA) & (2 * H_PATCH - 1));
+            const bool first = j < n1;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? p.S1 : p.S2), 0, first ? p.bytesS1 : p.bytesS2, 0x00020000);
+            const unsigned cs2 = (unsigned)(first ? p.c1s : p.c2s) * 2u, so = (unsigned)(first ? j : j - n1) * (BK * 2u);
+#pragma unroll
+            for (int r = 0; r < H_LSA; ++r) blds16(rs, j < nsc ? (unsigned)spix[r] * cs2 + ssw[r] : 0x80000000u, so, dst + (r * H_LW + s) * 1024);
+        };
         auto stage_p = [&](int buf, int c, bool real) __attribute__((always_inline)) {
             char* dst = smem + buf * H_PATCH;
 #pragma unroll
             for (int r = 0; r < H_LP; ++r) blds16(rsA, real ? poff[r] : 0x80000000u, (unsigned)c * (BK * 2), dst + (r * H_LW + s) * 1024);
         };
         // weight K-tile (chunk c, tap t): channels [64 c, 64 c + 64) of tap t of every output row -- OHWI rows of 9 * Cin elements
+        // (c == nchunks: shortcut K-tile t -- the shortcut tensors' channels sit behind the nine taps in every weight row)
         auto stage_w = [&](int slot, int c, int t) __attribute__((always_inline)) {
             char* dst = smem + H_OFF_W + slot * H_WT;
 #ifdef TMIX_ABL_WSEQ      // dev A/B builds only (wrong results, timing valid): the weight K-tiles read as if the rows were stored chunk-major, i.e. consecutive 128-byte pieces
             const unsigned so = (unsigned)(c * 9 + t) * (BK * 2u);
 #else
-            const unsigned so = (unsigned)(t * p.Cin + c * BK) * 2u;
+            const unsigned so = c < nchunks ? (unsigned)(t * p.Cin + c * BK) * 2u : (unsigned)(9 * p.Cin + t * BK) * 2u;
 #endif
 #pragma unroll
             for (int r = 0; r < H_LWI; ++r) blds16(rsW, woff[r], so, dst + (r * H_LW + s) * 1024);
         };
-        const int nk = nchunks * 9;
+        const int nk = nchunks * 9 + nsc;
         // prologue: patch 0 and weight tiles 0, 1 in front of the first barrier, tile 2 behind it (as tiling 21: the math waves start as soon as tile 0 is there)
         stage_p(0, 0, true);
         stage_w(0, 0, 0);
@@ -141,14 +166,26 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
             for (int t = 0; t < 9; ++t) {
                 const int kt = c * 9 + t;
                 const bool more = kt + 3 < nk;
+                const bool sc_next = nsc > 0 && c == nchunks - 1;     // behind the last chunk come shortcut tiles: their first two A tiles instead of a patch
                 if (more) stage_w(slot3, c3, t3);
-                if (t == 0) stage_p((c + 1) & 1, c + 1, c + 1 < nchunks);
-                if (more) { if (t <= 2) wait_vmcnt<2 * H_LWI + H_LP>(); else wait_vmcnt<2 * H_LWI>(); }
+                if (t == 0) { if (sc_next) { stage_sa(0); stage_sa(1); } else stage_p((c + 1) & 1, c + 1, c + 1 < nchunks); }
+                if (more) { if (t <= 2) { if (sc_next) wait_vmcnt<2 * H_LWI + 2 * H_LSA>(); else wait_vmcnt<2 * H_LWI + H_LP>(); } else wait_vmcnt<2 * H_LWI>(); }
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 slot3 = (slot3 + 1) & 3;
-                if (++t3 == 9) { t3 = 0; ++c3; }
+                if (c3 < nchunks) { if (++t3 == 9) { t3 = 0; ++c3; } } else ++t3;
             }
+        }
+        // shortcut K-tiles: tile j reads weight tile nk_main + j and A slot j % 3; A tile j + 2 goes to the slot tile j - 1 read (its barrier is behind us).  The wait
+        // makes weight tile kt + 1 AND A tile j + 1 (issued one iteration ago, behind weight tile kt + 2) visible: only what this iteration issued may stay in flight
+        for (int j = 0; j < nsc; ++j) {
+            const bool more_w = j + 3 < nsc, more_a = j + 2 < nsc;
+            if (more_w) stage_w(slot3, c3, t3);
+            if (more_a) stage_sa(j + 2);
+            if (more_w) wait_vmcnt<H_LWI + H_LSA>(); else if (more_a) wait_vmcnt<H_LSA>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            slot3 = (slot3 + 1) & 3;
+            ++t3;
         }
         return;
     }
@@ -241,6 +278,36 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
             kstep(1, t == 8 ? (buf ^ 1) : buf, t == 8 ? 0 : t + 1, cur, 0);
         }
     }
+    if (nsc > 0) {
+        // ---- shortcut K-tiles: dense A tiles (row w * 32 + l31 of the slot, the swizzle of the W rows), same weight ring
+        const int offS = (w * 32 + l31) * 128;
+        auto rd_as = [&](int j, int kk) __attribute__((always_inline)) -> frag_ab {
+            return *(const frag_ab*)(smem + ((sa_base + (j % 3) * H_SA) & (2 * H_PATCH - 1)) + offS + ((((kk * 2) + lhi) ^ fsw) << 4));
+        };
+        auto kstep_s = [&](const int S, const int nj, const int ns, const int nkk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j], fa[S], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) fa[1 - S] = rd_as(nj, nkk);
+                fb[1 - S][j] = rd_b(ns, j, nkk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        fa[0] = rd_as(0, 0);                               // (the main loop's last k-step fetched a stale patch row here; the W fragments of tile 0 are already right)
+        for (int j = 0; j < nsc; ++j) {
+            kstep_s(0, j, cur, 1);
+            kstep_s(1, j, cur, 2);
+            kstep_s(0, j, cur, 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            cur = (cur + 1) & 3;
+            kstep_s(1, j + 1, cur, 0);
+        }
+    }
     if (prof_on) pt2 = prof_now();
 
     // ---- staged epilogue (the straight-line form of gemm_kernel.h, FM = 1, FN = 5).  32 x 32 accumulator: lane holds pixel l31, output channels
@@ -317,7 +384,7 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
 
 // can the halo-patch kernel run this convolution?
 bool convh_eligible(const Params& p, int conv, int f8) {
-    return conv && !f8 && p.mode == TMIX_CONV_S1 && p.ntaps == 9 && !p.S1 && !p.scaleA && (p.wide & 1) && (p.Wo % H_TC) == 0 && (p.Ho % H_TR) == 0 && (p.N % H_BN) == 0
+    return conv && !f8 && p.mode == TMIX_CONV_S1 && p.ntaps == 9 && !p.scaleA && (p.wide & 1) && (p.Wo % H_TC) == 0 && (p.Ho % H_TR) == 0 && (p.N % H_BN) == 0
            && (p.Cin % BK) == 0 && (!p.rgb || p.rows_per_group % (p.Ho * p.Wo) == 0) && (!p.R || ((p.ldr % 8) == 0 && aligned16(p.R)));
 }
 
