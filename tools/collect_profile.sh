@@ -23,7 +23,7 @@ for pm in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != pm: continue
         n = r["Kernel_Name"]
         m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
-        key = ("conv" if m.group(1).split(",")[5].strip() == "1" else "gemm") if m else "gemm" if ("gemm_qattn_kernel" in n or "gemm_w22_kernel" in n) else "attn" if ("attn_fwd" in n or "attn_small" in n) else "norm" if "gn_" in n else None
+        key = ("conv" if m.group(1).split(",")[5].strip() == "1" else "gemm") if m else "gemm" if ("gemm_qattn_kernel" in n or "gemm_w22_kernel" in n) else "conv" if "conv_halo_kernel" in n else "attn" if ("attn_fwd" in n or "attn_small" in n) else "norm" if "gn_" in n else None
         if key:
             agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
     res[pm] = {k: {"launches": v[0], "sum_kb": v[1], "avg_kb_per_launch": v[1] / max(1, v[0])} for k, v in agg.items()}
@@ -51,7 +51,7 @@ for r in csv.DictReader(open(f"{out}/{tag}_MFMA_counter_collection.csv")):
     if r["Counter_Name"] != "MfmaUtil": continue
     n = r["Kernel_Name"]
     m = re.search(r"gemm_conv_kernel<([^>]*)>", n)
-    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "gemm<qattn:64x320,to_q+cross-attention>" if "gemm_qattn_kernel" in n else "gemm<w22:128x160,2x2>" if "gemm_w22_kernel" in n else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else None
+    key = ("gemm<" if m and m.group(1).split(",")[5].strip() == "0" else "conv<") + m.group(1).replace(" ", "") + ">" if m else "gemm<qattn:64x320,to_q+cross-attention>" if "gemm_qattn_kernel" in n else "gemm<w22:128x160,2x2>" if "gemm_w22_kernel" in n else "conv<halo:4x32px,160>" if "conv_halo_kernel" in n else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else None
     if key: agg[key].append((float(r["Counter_Value"]), dur.get(r["Dispatch_Id"], 1.0)))
 cls = collections.defaultdict(list)
 for k, v in agg.items(): cls[k.split("<")[0]] += v

@@ -24,7 +24,7 @@ for name in ("video", "fp8"):
                 a = [x.strip() for x in m.group(1).split(",")]
                 key = ("conv" if a[5] == "1" else "gemm") + ("_fp8" if int(a[7]) >= 2 else "") + "<" + ",".join(a) + ">"
             else:
-                key = "gemm<qattn:64x320,to_q+cross-attention>" if "gemm_qattn_kernel" in n else "gemm<w22:128x160,2x2>" if "gemm_w22_kernel" in n else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else "temporal_attn" if "temporal" in n else None
+                key = "gemm<qattn:64x320,to_q+cross-attention>" if "gemm_qattn_kernel" in n else "gemm<w22:128x160,2x2>" if "gemm_w22_kernel" in n else "conv<halo:4x32px,160>" if "conv_halo_kernel" in n else "attn_fwd" if "attn_fwd" in n else "attn_small" if "attn_small" in n else "temporal_attn" if "temporal" in n else None
             if key: agg[key].append((float(r["Counter_Value"]), dur.get(r["Dispatch_Id"], 1.0)))
         cls = collections.defaultdict(list)
         for k, v in agg.items(): cls[k.split("<")[0]] += v
