@@ -253,7 +253,11 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j], fa[S], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 0) fa[1 - S] = rd_a(nb, nt, nkk);
+#ifdef TMIX_HALO_ABL_LDS      // dev A/B builds only (wrong results): 16 instead of 24 fragment reads per K-tile -- is the loop bound by LDS read bytes?
+            if (j < 3) fb[1 - S][j] = rd_b(ns, j, nkk); else fb[1 - S][j] = fb[1 - S][j - 3];
+#else
             fb[1 - S][j] = rd_b(ns, j, nkk);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };

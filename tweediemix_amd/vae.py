@@ -357,9 +357,13 @@ class VAEEncoderPlan(VAEDecoderPlan):
                    self.moments.data_ptr(), B, ci, Hh, Ww, 2 * cfg["latent_channels"])
 
     def __call__(self, image):
-        """-> (mean, logvar) after quant_conv (an 8x8 per-pixel map on the 1/8-resolution moments: a torch einsum on a 64x64 grid)."""
+        """-> (mean, logvar) after quant_conv (an 8x8 per-pixel map on the 1/8-resolution moments, once per video: tmix_linear_f32 over 256-pixel row blocks --
+        the product reaches no torch matmul / hipBLASLt anywhere)."""
         self.image.copy_(image)
         self.run()
-        m = torch.einsum("oc,bchw->bohw", self.qw, self.moments) + self.qb[None, :, None, None]
+        B, C2, h, w = self.moments.shape
+        rows = self.moments.permute(0, 2, 3, 1).reshape(B * h * w, C2).contiguous()
+        out = torch.cat([ops.linear_f32(rows[i:i + 256], self.qw, self.qb) for i in range(0, rows.shape[0], 256)])
+        m = out.view(B, h, w, C2).permute(0, 3, 1, 2)
         lc = self.cfg["latent_channels"]
         return m[:, :lc].contiguous(), m[:, lc:].clamp(-30.0, 20.0).contiguous()
