@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if getattr(config.option, "durations", None) is None:      # the 15 slowest tests in every log (the GPU suite ran 1017 s of the driver's 1200 s limit)
+        config.option.durations = 15
+        config.option.durations_min = 1.0
     # The fp32 ORACLES (oracle/*.py: stock torch ops) run their convolutions on the GPU box too.  Through MIOpen every new fp32 conv configuration is searched /
     # JIT-compiled on first use on a fresh box (no kernel cache travels): tens of seconds per full-size oracle (the 1024^2 VAE decode: 80 s of a 590 s suite,
     # 1017 s on the driver's box in round 5).  With the MIOpen path off torch runs them as unfold + rocBLAS GEMM: deterministic cost, nothing compiled.  The PRODUCT
