@@ -252,16 +252,26 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
         for (int j = 0; j < 5; ++j) {
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j], fa[S], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (j == 0) fa[1 - S] = rd_a(nb, nt, nkk);
 #ifdef TMIX_HALO_ABL_LDS      // dev A/B builds only (wrong results): 16 instead of 24 fragment reads per K-tile -- is the loop bound by LDS read bytes?
+            if (j == 0) fa[1 - S] = rd_a(nb, nt, nkk);
             if (j < 3) fb[1 - S][j] = rd_b(ns, j, nkk); else fb[1 - S][j] = fb[1 - S][j - 3];
-#else
+#elif defined(TMIX_HALO_READS_EVEN)     // dev A/B builds: one W fragment behind every MFMA (the first form)
+            if (j == 0) fa[1 - S] = rd_a(nb, nt, nkk);
             fb[1 - S][j] = rd_b(ns, j, nkk);
+#else
+            // the six reads of the next k-step behind the FIRST three MFMAs (two each, as the lock-step loops of gemm_kernel.h deal them): the last one is then two
+            // MFMAs old when the K-tile's hand-over waits for lgkmcnt(0), instead of zero
+            if (j == 0) { fa[1 - S] = rd_a(nb, nt, nkk); fb[1 - S][0] = rd_b(ns, 0, nkk); }
+            else if (j == 1) { fb[1 - S][1] = rd_b(ns, 1, nkk); fb[1 - S][2] = rd_b(ns, 2, nkk); }
+            else if (j == 2) { fb[1 - S][3] = rd_b(ns, 3, nkk); fb[1 - S][4] = rd_b(ns, 4, nkk); }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     int cur = 0;
+#ifdef TMIX_HALO_PRIO         // dev A/B builds: the math waves above the loader wave of their SIMD in the issue arbiter
+    __builtin_amdgcn_s_setprio(2);
+#endif
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
 #pragma unroll
@@ -293,8 +303,9 @@ __global__ void __launch_bounds__((H_NW + H_LW) * 64, 2) conv_halo_kernel(const 
             for (int j = 0; j < 5; ++j) {
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j], fa[S], acc[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (j == 0) fa[1 - S] = rd_as(nj, nkk);
-                fb[1 - S][j] = rd_b(ns, j, nkk);
+                if (j == 0) { fa[1 - S] = rd_as(nj, nkk); fb[1 - S][0] = rd_b(ns, 0, nkk); }
+                else if (j == 1) { fb[1 - S][1] = rd_b(ns, 1, nkk); fb[1 - S][2] = rd_b(ns, 2, nkk); }
+                else if (j == 2) { fb[1 - S][3] = rd_b(ns, 3, nkk); fb[1 - S][4] = rd_b(ns, 4, nkk); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
