@@ -345,6 +345,11 @@ _TUNE_CACHE = {}      # repr((kind, shape key)) -> best TMIX_TILE_* id, shared b
 # out 3 % slower than with 128x128 / 128x160 grids that leave CUs to the sibling.  Entries measured for a chain that shares
 # the chip carry this prefix; a shape without one falls back to the plain entry unless that is an exclusive tiling.
 SHARED = "shared|" 
+# A third context since round 6: the launches of a plan whose projections read one weight set PER BATCH ROW (the LoRA-routed fusion step).  The same launch shape
+# can want another tiling there: FF2 on the 2 x 2-wave tiling 23 is 0.46 ms per step FASTER in the Custom-Diffusion step and 0.30 ms SLOWER in the routed LoRA step
+# (three interleaved rounds on one box, profiles/r6_experiments/table_variants_routed_context.txt) -- behind it sits a q/k/v launch with four 9.8 MB weight sets, and
+# tiling 23's four loader waves queue that launch's weight touches in front of their first K-tile.  Entries with this prefix win for routed plans; without one the plain entry applies.
+ROUTED = "routed|"
 _TUNE_FILE = os.environ.get("TMIX_TUNE_FILE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json"))
 
 
@@ -371,7 +376,7 @@ def tune_lookup(ctx, key):
     c = _TUNE_CACHE.get(ctx + key)
     if c is None and ctx:
         c = _TUNE_CACHE.get(key)
-        if c in L.TILE_EXCLUSIVE:
+        if ctx == SHARED and c in L.TILE_EXCLUSIVE:
             c = None
     return c
 
@@ -398,11 +403,12 @@ class UNetPlan:
         self.fp8_conv = not os.environ.get("TMIX_FP8_NO_CONV")         # =1: every convolution on bf16 operands (before round 4's tmix_conv3x3_nhwc_fp8)
         self.fp8_conv_tile = int(os.environ.get("TMIX_FP8_CONV_TILE", "20"))   # 128 x 160 with two loader waves (12: without)
         self.fp8_tile = int(os.environ.get("TMIX_FP8_TILE", "21"))      # 128 x 160 e4m3 tiling of the N = 1280 / 640 launches (21: loader waves, 12: none, 0: phase-offset only)
-        self.tune_ctx = SHARED if shared else ""      # this chain runs beside a sibling chain (PlanGroup member)
         self.kv = kv
         # LoRA routing: batch row b uses merged weight set row_sets[b] (default: row b of a single seed)
         self.row_sets = list(row_sets) if row_sets is not None else list(range(B))
         self.routed = bool(routed) and W.kind == "lora" and len(self.row_sets) == B and max(self.row_sets) <= W.K
+        # tile-table context: this chain runs beside a sibling chain (PlanGroup member) / its projections are concept-routed / neither
+        self.tune_ctx = SHARED if shared else (ROUTED if (self.routed and getattr(W, "lora_mode", "merged") != "lowrank") else "")
         # low-rank LoRA (UNetWeights.lora_mode): the routed projections run on SHARED weights over K + 64 input columns; the concept of a
         # batch row only decides what tmix_lora_down writes into the pad columns of its rows
         self.lowrank = self.routed and getattr(W, "lora_mode", "merged") == "lowrank"
@@ -1254,7 +1260,7 @@ def tilings_follow_table(plan):
         c = table.get(ctx + key)
         if c is None and ctx:
             c = table.get(key)
-            if c in L.TILE_EXCLUSIVE:
+            if ctx == SHARED and c in L.TILE_EXCLUSIVE:
                 c = None
         return c
 
