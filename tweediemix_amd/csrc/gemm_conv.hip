@@ -21,7 +21,8 @@ int launch(int conv, Params& p, int batch, int cfg, hipStream_t st) {
     // 23 = 128x160 over 2 x 2 math waves of 64x80 (v_mfma_f32_16x16x32_bf16) + four loader waves (gemm_w22.hip): the staged plain bf16 epilogue only
     // 26 = the halo-patch convolution (gemm_convh.hip): stride 1, bf16, 4 x 32 pixel tiles; anything it does not carry runs as the loader-wave tilings 20 (conv) / 21 (GEMM)
     if (cfg == 26) { if (convh_eligible(p, conv, p.scaleA != nullptr)) return launch_convh(p, st); cfg = conv ? 20 : 21; }
-#ifdef TMIX_EXPERIMENTAL_TILINGS      // dev variants (make EXPERIMENTAL=1): 24 = 256x320 on persistent workgroups (gemm_ff1p.hip), 25 = tiling 23 with an L2 prefetcher wave
+#ifdef TMIX_EXPERIMENTAL_TILINGS      // dev variants (make EXPERIMENTAL=1): 24 = 256x320 on persistent workgroups (gemm_ff1p.hip), 25 = tiling 23 with an L2 prefetcher wave,
+    // 27 (asked for as tile_cfg 27 through the 13 slot: TMIX_TILE13_NS2) = 64x160 over five waves with a TWO-deep ring, two workgroups per CU (VERDICT r5 item 6 i)
     if (cfg == 23 || cfg == 25) { if (w22_eligible(p, conv, 0)) return launch_w22(p, batch, st, cfg == 25); cfg = conv ? 12 : 21; }
     if (cfg == 24) { if (ff1p_eligible(p, conv, 0, batch)) return launch_ff1p(p, st); cfg = 14; }
 #else                                 // the shipped library: ids 24 / 25 are reserved and run as the tilings they were variants of (same bits)

@@ -31,13 +31,17 @@ struct QAParams {
 
 namespace {
 
+#ifdef TMIX_QATTN_H4      // dev A/B builds (VERDICT r5 item 6 ii): FOUR heads per tile -- 64 x 256, four math + four loader waves, 40 KB K-tiles, 320 tiles at M = 4096 (1.25 rounds)
+constexpr int Q_BM = 64, Q_BN = 256, Q_NS = 3, Q_NW = 4, Q_LW = 4;
+#else
 constexpr int Q_BM = 64, Q_BN = 320, Q_NS = 3, Q_NW = 5, Q_LW = 3;
+#endif
 constexpr int Q_ATILE = Q_BM * 128, Q_BTILE = Q_BN * 128, Q_STAGE = Q_ATILE + Q_BTILE, Q_RING = Q_NS * Q_STAGE;
 constexpr int Q_IA = Q_BM / 8, Q_IB = Q_BN / 8, Q_L = (Q_IA + Q_IB) / Q_LW;         // 8 + 40 LDS-DMA instructions per K-tile, 16 per loader
 static_assert((Q_IA + Q_IB) % Q_LW == 0 && (Q_NS - 2) * Q_L <= 63, "loader geometry");
 constexpr int Q_LDV = 80;                           // keys per V^T row (Skv <= 80 rounded up to 8: the KV cache's leading dimension)
 constexpr int Q_VH = 64 * Q_LDV * 2;                // bytes of one head's V^T: 64 rows of 160 bytes, contiguous
-constexpr int Q_VBYTES = 5 * Q_VH;                  // 51,200 bytes at the front of the ring
+constexpr int Q_VBYTES = Q_NW * Q_VH;               // 51,200 bytes at the front of the ring (one V^T per head of the tile)
 constexpr int Q_SR = 64 * 4 + 16;                   // bytes per row of a wave's output patch (64 fp32 columns + pad)
 constexpr int Q_PATCH = 32 * Q_SR;
 constexpr int Q_POFF = (Q_VBYTES + 1023) / 1024 * 1024;
