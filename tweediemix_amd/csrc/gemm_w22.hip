@@ -53,7 +53,12 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
     unsigned pf_keep[PFU];
 #pragma unroll
     for (int u = 0; u < PFU; ++u) pf_keep[u] = 0;
-    if (p.pf && loader) {
+#ifdef TMIX_W22_PF_MATH
+    const bool pf_here = false;
+#else
+    const bool pf_here = loader;
+#endif
+    if (p.pf && pf_here) {
         const long long nwg = (long long)gridDim.x * gridDim.y, nth = W_LW * 64;
         const long long lines = (p.pf_bytes + 127) >> 7; const int per = p.pf_per;
         const long long first = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * nth + (tid - W_NW * 64);
@@ -237,6 +242,21 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
             }
     };
 
+#ifdef TMIX_W22_PF_MATH
+    // (dev variant) the touches ride in the MATH waves' queue, which nothing waits on until the residual rows are asked for: the loaders' first K-tile is not behind them
+    unsigned pf_sink = 0;
+    if (p.pf) {
+        static_assert(W_NW == W_LW, "the host deals the lines out over W_LW * 64 threads per workgroup");
+        const long long nwg = (long long)gridDim.x * gridDim.y, nth = W_NW * 64;
+        const long long lines = (p.pf_bytes + 127) >> 7; const int per = p.pf_per;
+        const long long first = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * nth + tid;
+#pragma unroll
+        for (int u = 0; u < PFU; ++u) {
+            const long long ln = first + (long long)u * nwg * nth;
+            if (u < per && ln < lines) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(p.pf + (ln << 7)) : "memory");
+        }
+    }
+#endif
     __builtin_amdgcn_s_barrier();                      // K-tile 0 has landed
     asm volatile("" ::: "memory");
     if (prof_on) pt1 = prof_now();
@@ -262,6 +282,9 @@ __global__ void __launch_bounds__((W_NW + W_LW) * 64, 2) gemm_w22_kernel(const P
     };
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef TMIX_W22_PF_MATH
+        if (kt == nk - 1) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
         if (kt == nk - 1) { epi_prefetch(); __builtin_amdgcn_sched_barrier(0); }
         kstep(0, cur, c1);
         // every fragment of tile kt is in registers (its ring slot may be restaged after the barrier); tile kt + 1 has landed
