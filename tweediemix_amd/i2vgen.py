@@ -245,6 +245,8 @@ class I2VPlan(UNetPlan):
         self.fp8 = False                                 # (the fp8 projections are wired for the image UNet only)
         self._tunable, self._ln_links, self._vt = [], [], {}
         self._pf_prev, self._pf_on = None, not os.environ.get("TMIX_NO_PREFETCH")      # next-launch weight prefetch hints (UNetPlan._hint_weights)
+        self._pf_cap = int(float(os.environ.get("TMIX_PF_CAP_MB", "0")) * (1 << 20))    # (whole tensors: a clip's launches last 50 - 800 us, UNetPlan.__init__)
+        self._pf_cap_over = int(float(os.environ.get("TMIX_PF_CAP_OVER_MB", "20")) * (1 << 20))
         self.kv = _KV(W, context, frames)
         self.x_in = torch.zeros(B, 2 * cfg.in_channels, h, w, device=dev, dtype=F32)
         self.x_in.view(clips, frames, 2 * cfg.in_channels, h, w)[:, :, cfg.in_channels:] = il_feat.to(dev, F32).permute(0, 2, 1, 3, 4)

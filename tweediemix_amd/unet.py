@@ -454,6 +454,13 @@ class UNetPlan:
         # when that launch is planned): the chain otherwise meets every weight cold from HBM (TMIX_NO_PREFETCH=1 switches it off)
         self._pf_prev = None
         self._pf_on = not os.environ.get("TMIX_NO_PREFETCH")
+        # How much of a LARGE weight tensor a hint names (round 6, profiles/r6_experiments/weight_hint_cap_*.txt): a launch of a single-seed call lasts 20 - 90 us, and
+        # touching the 39 MB of a routed q/k/v weight (or FF1's 26 MB) inside it costs the hinting launch more than the hinted one gains -- tensors over 20 MB
+        # are named by their first 8 MB there (1 MB ... 12 MB measure the same; 13 MB tensors want all of themselves: capping those loses 0.5 - 1 ms).  The co-batched
+        # calls (launches of 0.2 - 1 ms) keep whole-tensor hints.  TMIX_PF_CAP_MB / TMIX_PF_CAP_OVER_MB override (cap 0: whole tensors everywhere).
+        small_call = B * h * w <= 4 * 128 * 128
+        self._pf_cap = int(float(os.environ.get("TMIX_PF_CAP_MB", "8" if small_call else "0")) * (1 << 20))
+        self._pf_cap_over = int(float(os.environ.get("TMIX_PF_CAP_OVER_MB", "20")) * (1 << 20))
         # GroupNorm statistics come from the launch that WRITES the normalised tensor (col_stats_out of the conv / proj_out epilogue), so a
         # norm is two launches (combine partials, apply) and one pass over x instead of three and two (TMIX_GN_STATS_KERNEL=1: the old form)
         self._gn_fused = not os.environ.get("TMIX_GN_STATS_KERNEL")
@@ -544,7 +551,8 @@ class UNetPlan:
         if not self._pf_on:
             return
         if self._pf_prev is not None:
-            self._pf_prev[0], self._pf_prev[1] = w.data_ptr(), w.numel() * w.element_size()
+            nbytes = w.numel() * w.element_size()
+            self._pf_prev[0], self._pf_prev[1] = w.data_ptr(), min(nbytes, self._pf_cap) if self._pf_cap and nbytes > self._pf_cap_over else nbytes
         self._pf_prev = [None, 0]
         self.keep.append(w)
         self.ops.append((self.lib.tmix_gemm_prefetch_next, self._pf_prev))
