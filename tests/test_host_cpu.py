@@ -334,3 +334,25 @@ def test_partition_masks_are_a_convex_blend_and_keep_the_oracle_latent_bounded()
         return float(np.abs(x).max())
     bounded, exploding = run("partition"), run("overlap")
     assert bounded < 10.0 and exploding > 20 * bounded, (bounded, exploding)          # 13 fusion steps at weight 2 on the overlap
+
+
+
+def test_weight_hint_policy_caps_large_tensors_of_single_seed_calls_only(monkeypatch):
+    """UNetPlan's weight hints: single-seed calls name 8 MB of tensors over 20 MB, co-batched calls whole tensors; the env knobs override both."""
+    from tweediemix_amd import unet as U
+    monkeypatch.delenv("TMIX_PF_CAP_MB", raising=False); monkeypatch.delenv("TMIX_PF_CAP_OVER_MB", raising=False)
+    MB = 1 << 20
+    cap, over = U.hint_policy(4, 128, 128)
+    assert (cap, over) == (8 * MB, 20 * MB)
+    assert U.hint_bytes(39 * MB, cap, over) == 8 * MB            # four merged q/k/v weight sets
+    assert U.hint_bytes(26 * MB + 1, cap, over) == 8 * MB        # FF1
+    assert U.hint_bytes(13 * MB, cap, over) == 13 * MB           # FF2 / routed out-projections: whole (capping these measured 0.5 - 1 ms slower)
+    assert U.hint_bytes(20 * MB, cap, over) == 20 * MB
+    cap, over = U.hint_policy(32, 128, 128)                      # 8 co-batched seeds
+    assert cap == 0 and U.hint_bytes(39 * MB, cap, over) == 39 * MB
+    assert U.hint_policy(2, 128, 128)[0] == 8 * MB and U.hint_policy(16, 128, 128)[0] == 0
+    monkeypatch.setenv("TMIX_PF_CAP_MB", "0")
+    assert U.hint_policy(4, 128, 128)[0] == 0
+    monkeypatch.setenv("TMIX_PF_CAP_MB", "1.5"); monkeypatch.setenv("TMIX_PF_CAP_OVER_MB", "12")
+    cap, over = U.hint_policy(32, 128, 128)
+    assert (cap, over) == (3 * MB // 2, 12 * MB) and U.hint_bytes(13 * MB, cap, over) == 3 * MB // 2

@@ -384,6 +384,20 @@ def tune_lookup(ctx, key):
 load_tune_table()
 
 
+def hint_policy(B, h, w):
+    """(cap, over) in bytes for the weight hints of a UNet call of B latents of h x w: tensors larger than `over` are named by their first `cap`
+    bytes (cap 0: whole tensors).  See UNetPlan.__init__ for the measurements behind the defaults; TMIX_PF_CAP_MB / TMIX_PF_CAP_OVER_MB override."""
+    small_call = B * h * w <= 4 * 128 * 128
+    cap = int(float(os.environ.get("TMIX_PF_CAP_MB", "8" if small_call else "0")) * (1 << 20))
+    over = int(float(os.environ.get("TMIX_PF_CAP_OVER_MB", "20")) * (1 << 20))
+    return cap, over
+
+
+def hint_bytes(nbytes, cap, over):
+    """bytes of an `nbytes` weight tensor that the launch in front of its consumer touches (tmix_gemm_prefetch_next)"""
+    return min(nbytes, cap) if cap and nbytes > over else nbytes
+
+
 class UNetPlan:
     """One UNet call shape: batch B, latent h x w, a KV cache (prompt rows) and a routing flag.
 
@@ -458,9 +472,7 @@ class UNetPlan:
         # touching the 39 MB of a routed q/k/v weight (or FF1's 26 MB) inside it costs the hinting launch more than the hinted one gains -- tensors over 20 MB
         # are named by their first 8 MB there (1 MB ... 12 MB measure the same; 13 MB tensors want all of themselves: capping those loses 0.5 - 1 ms).  The co-batched
         # calls (launches of 0.2 - 1 ms) keep whole-tensor hints.  TMIX_PF_CAP_MB / TMIX_PF_CAP_OVER_MB override (cap 0: whole tensors everywhere).
-        small_call = B * h * w <= 4 * 128 * 128
-        self._pf_cap = int(float(os.environ.get("TMIX_PF_CAP_MB", "8" if small_call else "0")) * (1 << 20))
-        self._pf_cap_over = int(float(os.environ.get("TMIX_PF_CAP_OVER_MB", "20")) * (1 << 20))
+        self._pf_cap, self._pf_cap_over = hint_policy(B, h, w)
         # GroupNorm statistics come from the launch that WRITES the normalised tensor (col_stats_out of the conv / proj_out epilogue), so a
         # norm is two launches (combine partials, apply) and one pass over x instead of three and two (TMIX_GN_STATS_KERNEL=1: the old form)
         self._gn_fused = not os.environ.get("TMIX_GN_STATS_KERNEL")
@@ -551,8 +563,7 @@ class UNetPlan:
         if not self._pf_on:
             return
         if self._pf_prev is not None:
-            nbytes = w.numel() * w.element_size()
-            self._pf_prev[0], self._pf_prev[1] = w.data_ptr(), min(nbytes, self._pf_cap) if self._pf_cap and nbytes > self._pf_cap_over else nbytes
+            self._pf_prev[0], self._pf_prev[1] = w.data_ptr(), hint_bytes(w.numel() * w.element_size(), self._pf_cap, self._pf_cap_over)
         self._pf_prev = [None, 0]
         self.keep.append(w)
         self.ops.append((self.lib.tmix_gemm_prefetch_next, self._pf_prev))
