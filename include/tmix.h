@@ -178,6 +178,7 @@ int tmix_gemm_bf16(const tmix_gemm_desc* d, void* stream);
  * range split evenly over the grid -- so that the weights of the launch that FOLLOWS it are in the memory-side (Infinity) cache when that
  * launch starts (a dependent chain of launches otherwise meets every weight cold from HBM: fusion_sampling.py:340 calls the UNet's
  * ~490 Linear / Conv2d layers back to back).  Purely a performance hint: no effect on results; bytes <= 0 or NULL clears it.
+ * The touches share the hinting launch's memory queues: from a launch of tens of microseconds name a few MB of a large tensor rather than all of it.
  * `stream` is ignored (present so that the call has the shape of every other launch entry). */
 int tmix_gemm_prefetch_next(const void* next_weights, int64_t bytes, void* stream);
 /* The same GEMM on OCP fp8 (e4m3) operands -- the reference's precision bar is fp16 autocast (fusion_sampling.py:492); this is
