@@ -91,6 +91,33 @@ def test_groupnorm_statistics_from_the_producers_match_the_statistics_kernel(kin
     assert rel_l2(eps, ref) <= 2e-2 and rel_l2(eps, eps0) <= 1e-2
 
 
+def test_weight_hints_are_results_neutral_and_obey_the_cap(monkeypatch):
+    """tmix_gemm_prefetch_next names (part of) the next launch's weights (UNetPlan._hint_weights, unet.hint_policy): with whole-tensor hints, with a cap that bites on
+    this small network's tensors, and with no hints at all the call returns the same bits; every capped hint names at most the cap."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    def hints(plan):
+        return [a for fn, a in plan.ops if fn.__name__ == "tmix_gemm_prefetch_next"]
+    monkeypatch.setenv("TMIX_PF_CAP_MB", "0")
+    orc, plan, x, ehs, pooled, time_ids = make("lora", 4, 16, 16, True)
+    whole = [a[1] for a in hints(plan) if a[0]]
+    assert whole and max(whole) > 8192
+    eps_whole = plan(x.cuda(), 500).clone()
+    cap = 4096
+    monkeypatch.setenv("TMIX_PF_CAP_MB", str(cap / (1 << 20))); monkeypatch.setenv("TMIX_PF_CAP_OVER_MB", str(8192 / (1 << 20)))
+    _o, plan_c, *_ = make("lora", 4, 16, 16, True)
+    capped = [a[1] for a in hints(plan_c) if a[0]]
+    assert len(capped) == len(whole) and all(c == (cap if wb > 8192 else wb) for c, wb in zip(capped, whole)) and min(capped) < max(whole)
+    eps_capped = plan_c(x.cuda(), 500).clone()
+    monkeypatch.delenv("TMIX_PF_CAP_MB"); monkeypatch.delenv("TMIX_PF_CAP_OVER_MB"); monkeypatch.setenv("TMIX_NO_PREFETCH", "1")
+    _o, plan_n, *_ = make("lora", 4, 16, 16, True)
+    assert not hints(plan_n)
+    eps_none = plan_n(x.cuda(), 500).clone()
+    assert torch.equal(eps_whole, eps_capped) and torch.equal(eps_whole, eps_none)
+    ref = orc.forward(x, 500, ehs, pooled, time_ids, routed=True)
+    assert rel_l2(eps_whole.float().cpu(), ref) <= 2e-2
+
+
 @pytest.mark.parametrize("kind,hw", [("lora", (32, 32)), ("none", (8, 24))])
 def test_shortcut_in_the_conv_launch_matches_the_separate_gemm_and_concat(kind, hw, monkeypatch):
     """the default plan runs conv_shortcut inside conv2's launch (shortcut taps) and never writes the up-blocks' concatenations;
